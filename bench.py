@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — OH gridcells/s of the XGBoost-predict hot path on MI355X.
+
+A step = one pass of the hot path over the synthetic C360 L72 batch
+(55 987 200 gridcells x 27 float32 features, already resident in HBM as the
+row-major xx_carr the reference builds): OHXBoosterPredictDevice -> raw OH margins
+in HBM.  With N > 1 ranks (one process per GPU, launched by torch.distributed.run)
+the batch is cut into N contiguous row shards, every rank predicts its shard with a
+replicated booster, and one RCCL all-gather over xGMI reassembles the OH field on
+every GPU — that is part of the step.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the predict kernel against the
+HBM roofline with the ALGORITHMIC bytes of SURVEY.md §8(d): 112 B per gridcell plus
+8 B per node slot once per launch; `cpu_baseline` is the CPU oracle (own restatement
+of xgboost 1.6.0 semantics; "port") timed on this node's host cores on a bounded
+sample of the same rows.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+BYTES_PER_CELL = 112           # 27 x 4 B read + 4 B write
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", default="C360", help="BASELINE.json workload grid (default: the headline C360 L72)")
+    ap.add_argument("--kernel", default="auto", help="auto | wide | packed1 | packed2 | packed4")
+    ap.add_argument("--trees", type=int, default=100)
+    ap.add_argument("--depth", type=int, default=18)
+    ap.add_argument("--sample-log2", type=int, default=20)
+    ap.add_argument("--top-levels", type=int, default=None)
+    ap.add_argument("--line-slots", type=int, default=None)
+    ap.add_argument("--missing-ppm", type=int, default=0, help="inject -999.0/NaN at this rate per million entries")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--shuffle", action="store_true", help="permute the rows (destroys spatial coherence)")
+    return ap.parse_args()
+
+
+def cpu_baseline(model_image, rows_dev, budget_s):
+    """The oracle, all host cores (OpenMP), on the first S rows of the batch; S sized to the budget."""
+    from quickchem_amd import capi, synth
+    lib = capi.declare_xgb_api(C.CDLL(os.path.join(ROOT, "oracle", "lib", "liboracle_xgb.so")))
+    lib.oracle_num_threads.restype = C.c_int
+    cores = int(lib.oracle_num_threads())
+    booster = capi.Booster(model_buffer=model_image, lib=lib)
+
+    def run(n):
+        host = rows_dev[:n].cpu().numpy()
+        t0 = time.perf_counter()
+        d = capi.DMatrix(host, missing=synth.XX_MISS, lib=lib)     # XGDMatrixCreateFromMat is on the path
+        out = booster.predict(d)
+        d.free()
+        return time.perf_counter() - t0, out
+
+    probe = min(65536, rows_dev.shape[0])
+    t_probe, _ = run(probe)
+    rate = probe / max(t_probe, 1e-6)
+    n = int(min(rows_dev.shape[0], max(probe, rate * budget_s)))
+    n = max(64, n // 64 * 64)
+    t, out = run(n)
+    return {"value": n / t, "unit": "gridcells/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} rows of the batch, oracle/xgb_oracle.c (OpenMP, {cores} threads), "
+                      f"XGDMatrixCreateFromMat + XGBoosterPredict, {t:.2f} s"}, out, n
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from quickchem_amd import capi, shard, synth
+
+    grid = synth.GRIDS[args.grid]
+    n_total = grid[0] * grid[1] * grid[2]
+    row0, n_local = shard.row_shard(n_total, world, rank)
+
+    # ---- the booster: seeded synthetic OH model, identical on every rank ----
+    t0 = time.perf_counter()
+    model = synth.make_model(num_trees=args.trees, max_depth=args.depth, sample_log2=args.sample_log2)
+    booster = capi.Booster(model_buffer=model.image)
+    booster.set_param("ohx_kernel", args.kernel)
+    if args.top_levels is not None:
+        booster.set_param("ohx_top_levels", args.top_levels)
+    if args.line_slots is not None:
+        booster.set_param("ohx_line_slots", args.line_slots)
+    t_model = time.perf_counter() - t0
+
+    # ---- the batch: this rank's contiguous row shard, generated in HBM ----
+    rows = torch.empty((n_local, synth.NFEAT), dtype=torch.float32, device=dev)
+    synth.rows_device(grid, row0, n_local, rows)
+    if args.missing_ppm:
+        synth.inject_missing_device(rows, args.missing_ppm)
+    if args.shuffle:
+        perm = torch.randperm(n_local, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+        rows = rows[perm].contiguous()
+        del perm
+    torch.cuda.synchronize()
+    dmat = capi.DMatrix(device_ptr=rows.data_ptr(), nrow=n_local, ncol=synth.NFEAT, missing=synth.XX_MISS)
+    out_local = torch.empty(n_local, dtype=torch.float32, device=dev)
+    even = (n_total % world == 0)
+    out_full = torch.empty(n_total, dtype=torch.float32, device=dev) if world > 1 else out_local
+    stream = torch.cuda.current_stream()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev0[i].record(stream)
+        booster.predict_device(dmat, out_local.data_ptr(), stream=stream.cuda_stream)
+        if i is not None:
+            ev1[i].record(stream)
+        if world > 1:
+            shard.all_gather_rows(out_full, out_local, n_total, world, even)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    booster.check()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    kernel_s = float(np.mean(kernel_ms)) * 1e-3
+    if world > 1:
+        t = torch.tensor([kernel_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernel_s = float(t.item())
+
+    info = booster.info()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_total / (elapsed / args.steps)
+    algo_bytes = BYTES_PER_CELL * n_local + info["node_bytes"]
+    achieved = algo_bytes / kernel_s / 1e9
+
+    # ---- self-check + CPU baseline (rank 0, N = 1): the oracle on a bounded sample of the same rows ----
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu, want, n_chk = cpu_baseline(model.image, rows, args.cpu_seconds)
+        got = out_local[:n_chk].cpu().numpy()
+        if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+            raise SystemExit("bench: GPU margins differ from the oracle on the cpu_baseline sample")
+    if world > 1:
+        # every rank must hold the whole field, and the shards in row order
+        lo = out_full[row0:row0 + n_local]
+        if not torch.equal(lo.view(torch.int32), out_local.view(torch.int32)):
+            raise SystemExit("bench: all-gather did not put this rank's shard at its rows")
+
+    if rank == 0:
+        line = {
+            "metric": "OH gridcells/sec (XGBoost predict), C360 L72 batch",
+            "value": value, "unit": "gridcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.grid} L{grid[2]}: {n_total} gridcells x 27 float32 features (AoS rows in HBM), "
+                            f"{world} contiguous row shard(s)" + (", all-gather of the OH field" if world > 1 else ""),
+                "grid": list(grid), "rows_total": n_total, "rows_per_gpu": n_local,
+                "model": {"trees": info["num_trees"], "max_depth": info["max_depth"], "nodes": info["num_nodes"],
+                          "node_slots": info["num_slots"], "node_bytes": info["node_bytes"],
+                          "mean_path": round(model.mean_path, 3), "seed": synth.MODEL_SEED,
+                          "build_s": round(t_model, 2)},
+                "kernel": args.kernel, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle),
+                "parallelism": f"rows{world}",
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "predict_rows_tile_kernel", "kernel_ms": kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+/*
+ * ohxgb.h — C ABI of libohxgb.so, the MI355X (gfx950) OH-chemistry predictor.
+ *
+ * Drop-in boundary: GEOS-ESM/QuickChem reaches XGBoost through the Fortran
+ * module xgb_fortran_api, which binds eleven XGBoost C-API symbols with
+ * ISO_C_BINDING.  libohxgb.so exports those same symbols, with the C signatures
+ * the bindings imply, so QuickChem links against it instead of libxgboost 1.6.0
+ * (reference Shared/CMakeLists.txt:8-12) without touching a line of Fortran.
+ * Each declaration below cites the reference binding it replaces
+ * (paths relative to the QuickChem tree).
+ *
+ * Everything computes on the GPU.  There is no CPU fallback: a compute call
+ * made where no HIP device is usable returns -1 and XGBGetLastError() says so.
+ *
+ * Conventions (xgboost 1.6.0 c_api.h): every function returns 0 on success and
+ * -1 on failure; the message is then available, per thread, from
+ * XGBGetLastError().  Handles are opaque pointers created by the library and
+ * released by the matching *Free call.
+ */
+#ifndef OHXGB_H_
+#define OHXGB_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* DMatrixHandle;
+typedef void* BoosterHandle;
+typedef uint64_t bst_ulong;
+
+/* ------------------------------------------------------------------------
+ * Part 1 — the XGBoost C-API subset QuickChem binds
+ * ------------------------------------------------------------------------ */
+
+/* Last error message of the calling thread.  Not bound by the reference (it
+ * only asserts rc == 0, OH_GridComp/OH_GridCompMod.F90:252-265,353-378). */
+const char* XGBGetLastError(void);
+
+/* Shared/xgb_fortran_api.F90:86-94, called at OH_GridCompMod.F90:251 (1x27
+ * dummy) and :347 (the N x 27 batch).  `data` is row-major [nrow][ncol]
+ * (Fortran xx_carr(27,N)); it is copied to HBM before the call returns, the
+ * caller may free it at once.  Entries equal to `missing`, or NaN, are missing
+ * values.  As in xgboost 1.6.0, +-inf in the data is an error unless `missing`
+ * is itself infinite. */
+int XGDMatrixCreateFromMat(const float* data, bst_ulong nrow, bst_ulong ncol, float missing, DMatrixHandle* out);
+
+/* Shared/xgb_fortran_api.F90:45-48, called at OH_GridCompMod.F90:264,377. */
+int XGDMatrixFree(DMatrixHandle handle);
+
+/* Shared/xgb_fortran_api.F90:98-103 and :107-112 (bound, unused by OH). */
+int XGDMatrixNumRow(DMatrixHandle handle, bst_ulong* out);
+int XGDMatrixNumCol(DMatrixHandle handle, bst_ulong* out);
+
+/* Shared/xgb_fortran_api.F90:35-40 and :53-58 (bound, unused by OH).
+ * SaveBinary writes this library's own dense container ("OHXDMAT1");
+ * CreateFromFile reads that container, or CSV text when the name ends in
+ * ".csv" or carries "?format=csv" (all columns are features). */
+int XGDMatrixSaveBinary(DMatrixHandle handle, const char* fname, int silent);
+int XGDMatrixCreateFromFile(const char* fname, int silent, DMatrixHandle* out);
+
+/* Shared/xgb_fortran_api.F90:76-82, called at OH_GridCompMod.F90:256.  The
+ * reference passes ONE handle by value with len == 0 ("setting this to 27
+ * results in a Seg Fault", :255): `dmats` is never dereferenced when len == 0,
+ * and cached matrices are not needed for prediction in any case. */
+int XGBoosterCreate(const DMatrixHandle dmats[], bst_ulong len, BoosterHandle* out);
+
+/* Shared/xgb_fortran_api.F90:116-119 (the reference leaves it commented out,
+ * OH_GridCompMod.F90:389-392). */
+int XGBoosterFree(BoosterHandle handle);
+
+/* Shared/xgb_fortran_api.F90:19-23, called at OH_GridCompMod.F90:261.  Format
+ * by extension as in xgboost 1.6.0: ".json" JSON, ".ubj" UBJSON (refused),
+ * anything else the legacy binary format of the production ".model"/".bin"
+ * files (OH_GridComp/OH_instance_OH.rc:17-20). */
+int XGBoosterLoadModel(BoosterHandle handle, const char* fname);
+
+/* Shared/xgb_fortran_api.F90:27-31 (bound, unused by OH). */
+int XGBoosterSaveModel(BoosterHandle handle, const char* fname);
+
+/* Same loader from memory (xgboost c_api.h; not bound by the reference). */
+int XGBoosterLoadModelFromBuffer(BoosterHandle handle, const void* buf, bst_ulong len);
+
+/* Shared/xgb_fortran_api.F90:62-72, called at OH_GridCompMod.F90:356 with
+ * option_mask = 0, ntree_limit = 0, training = 0 (:231-235).
+ *   option_mask: 0 normal, 1 output margin, 16 leaf indices; others refused.
+ *   ntree_limit: 0 = all trees.
+ * *out_result points at a host buffer owned by the booster, valid until the
+ * next predict on that booster or XGBoosterFree (the reference never frees
+ * it, :362,381).  *out_len = nrow (asserted at :359). */
+int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, unsigned ntree_limit, int training,
+                     bst_ulong* out_len, const float** out_result);
+
+/* xgboost c_api.h; not bound by the reference.  Understood names:
+ *   "ohx_kernel"      wide | packed1 | packed2 | packed4 (default packed4)
+ *   "ohx_top_levels"  breadth-first levels per tree before line packing
+ *   "ohx_line_slots"  node slots per packed line (0 = breadth-first only)
+ *   "ohx_device"      HIP device ordinal for this booster
+ * xgboost's own parameter names ("nthread", "predictor", ...) are accepted and
+ * ignored. */
+int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value);
+
+/* ------------------------------------------------------------------------
+ * Part 2 — device-resident and fused entry points (additive)
+ * ------------------------------------------------------------------------ */
+
+/* HIP device count, or -1 with an error message when HIP is unusable. */
+int OHXDeviceCount(int* out);
+
+/* As XGDMatrixCreateFromMat, but `d_data` already lives in HBM.  The matrix
+ * BORROWS the pointer (no copy); it must stay valid until XGDMatrixFree.
+ * The inf check of the host path is folded into the predict kernels instead:
+ * a predict on data holding +-inf fails. */
+int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong ncol, float missing, DMatrixHandle* out);
+
+/* Predict straight into device memory: d_out[nrow] margins (or [nrow][ntree]
+ * leaf ids with option_mask 16).  `stream` is a hipStream_t (NULL = default
+ * stream); the call only enqueues work.  OHXBoosterCheck surfaces errors the
+ * kernels raised (inf in the input). */
+int OHXBoosterPredictDevice(BoosterHandle handle, DMatrixHandle dmat, int option_mask, unsigned ntree_limit,
+                            float* d_out, void* stream);
+int OHXBoosterCheck(BoosterHandle handle, void* stream);
+
+/* The whole of predict_OH_with_XGB's RUN section in one kernel
+ * (OH_GridCompMod.F90:303-383): gathers the 27 MAPL fields in place (field f is
+ * (im,jm,km) Fortran order, or (im,jm) when is2d[f] != 0; feature order of
+ * :313-339), divides field `pl_feature` by 100 (Pa -> hPa, :314; pass -1 for
+ * none), predicts rows m = i + im*(j + jm*(k-k1)) for k = k1..k2 (1-based,
+ * inclusive, the slab of :300-301), and stores
+ *   oh_ml(i,j,k) = 10**pred * ohscale      (:369 and :1569)
+ * leaving the other levels of oh_ml untouched.  apply_pow10 = 0 stores the raw
+ * margin times ohscale instead.  margin (optional, may be NULL) receives the raw
+ * xx_pred(m).  Host-pointer form: stages through HBM and returns when oh_ml is
+ * complete.  Device form: all pointers are device pointers, work is enqueued. */
+int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], const int32_t is2d[], int nfield,
+                            int pl_feature, int im, int jm, int km, int k1, int k2, float missing, int apply_pow10,
+                            float ohscale, float* oh_ml, float* margin);
+int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fields[], const int32_t is2d[],
+                                  int nfield, int pl_feature, int im, int jm, int km, int k1, int k2, float missing,
+                                  int apply_pow10, float ohscale, float* d_oh_ml, float* d_margin, void* stream);
+
+/* Model facts for roofline accounting: info[0] trees, [1] nodes in the model,
+ * [2] node slots in HBM, [3] bytes of the node array the selected kernel reads,
+ * [4] max depth, [5] features, [6] 1 if the packed 8-byte format is in use. */
+int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]);
+
+/* Synthetic inputs of SURVEY.md §8(d), generated in HBM (device pointers):
+ * rows [nrows][27] for row_begin..row_begin+nrows of an (im,jm,km) grid, or one
+ * MAPL field (feature 0..26 in reference order, PL in Pa; feature -1 = TROPP). */
+int OHXSynthRowsDevice(uint32_t seed, int im, int jm, int km, bst_ulong row_begin, bst_ulong nrows, float* d_out,
+                       void* stream);
+int OHXSynthFieldDevice(uint32_t seed, int feature, int im, int jm, int km, float* d_out, void* stream);
+int OHXInjectMissingDevice(float* d_rows, bst_ulong count, uint32_t seed, uint32_t rate_per_million, float missing,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OHXGB_H_ */

@@ -1,0 +1,501 @@
+/*
+ * xgb_oracle.c — CPU ORACLE for the OH XGBoost-predict path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this.  The product (quickchem_amd/lib/libohxgb.so) never links, loads or calls
+ * it, and has no CPU path of its own.
+ *
+ * PARITY UNPINNED: the reference (GEOS-ESM/QuickChem @ 2024-11-08) holds no
+ * tests, golden vectors, fixtures or model files for this path, and the
+ * arithmetic lives in a dependency that is not vendored: xgboost, pinned
+ * "1.6.0 EXACT" (reference Shared/CMakeLists.txt:8).  This file restates the
+ * published algorithm of xgboost 1.6.0 at the reference's call sites
+ * (OH_GridComp/OH_GridCompMod.F90:251,256,261,264,347,356,377) and is checked
+ * against hand-computed vectors (tests/golden/) and against an independent numpy
+ * restatement (oracle/xgb_oracle.py); it has never been compared with a real
+ * libxgboost.
+ *
+ * It exports the same C symbols as the product so that one driver can be linked
+ * against either library:
+ *   XGDMatrixCreateFromMat  xgboost src/data/adapter.h (dense adapter) +
+ *                           src/data/data.cc SparsePage::Push: an entry is dropped
+ *                           when it is NaN or == missing; +-inf with a finite
+ *                           `missing` is an error.
+ *   XGBoosterLoadModel      src/c_api/c_api.cc (format by extension) +
+ *                           src/learner.cc / src/gbm/gbtree_model.cc /
+ *                           src/tree/tree_model.cc (legacy binary layout).
+ *                           JSON is handled by the numpy oracle only.
+ *   XGBoosterPredict        src/predictor/cpu_predictor.cc: rows in blocks of 64,
+ *                           preds[row] = base_score, then per tree IN ORDER
+ *                           preds[row] += leaf(row), all in float;
+ *                           src/predictor/predict_fn.h GetNextNode:
+ *                           missing -> DefaultChild(), else cleft + !(fvalue < split_cond).
+ * and, beyond the library boundary, oracle_predict_OH_with_XGB() restates the
+ * RUN section of predict_OH_with_XGB itself (OH_GridCompMod.F90:275-383).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_EXPORT __attribute__((visibility("default")))
+
+typedef uint64_t bst_ulong;
+
+static __thread char g_err[512];
+
+static int fail(const char* msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return -1;
+}
+
+/* ---------------------------------------------------------------- model */
+
+typedef struct {
+  int32_t parent, cleft, cright;
+  uint32_t sindex;
+  float info; /* leaf_value | split_cond */
+} RawNode;    /* 20 bytes, include/xgboost/tree_model.h RegTree::Node */
+
+typedef struct {
+  int32_t num_nodes;
+  RawNode* nodes;
+} OTree;
+
+typedef struct {
+  uint32_t magic;
+  int loaded;
+  float base_score;
+  uint32_t num_feature;
+  int32_t num_trees;
+  OTree* trees;
+  char objective[64];
+  float* pred; /* prediction buffer owned by the booster (c_api.cc keeps it thread-local) */
+  size_t pred_cap;
+} OBooster;
+
+typedef struct {
+  uint32_t magic;
+  uint64_t nrow, ncol;
+  float missing;
+  float* data; /* dense copy; an entry is "missing" iff NaN or == missing */
+} ODMatrix;
+
+#define BOOSTER_MAGIC 0x0B005715u
+#define DMAT_MAGIC 0x0D3A7A1Bu
+
+static void free_trees(OBooster* b) {
+  if (b->trees) {
+    for (int32_t i = 0; i < b->num_trees; ++i) free(b->trees[i].nodes);
+    free(b->trees);
+  }
+  b->trees = NULL;
+  b->num_trees = 0;
+  b->loaded = 0;
+}
+
+/* cursor over the file image */
+typedef struct {
+  const uint8_t* p;
+  size_t len, off;
+} Cur;
+
+static int take(Cur* c, void* dst, size_t n) {
+  if (c->off + n > c->len) return -1;
+  if (dst) memcpy(dst, c->p + c->off, n);
+  c->off += n;
+  return 0;
+}
+
+static int take_string(Cur* c, char* dst, size_t cap) {
+  uint64_t n;
+  if (take(c, &n, 8)) return -1;
+  if (n > (1u << 20) || c->off + n > c->len) return -1;
+  size_t m = n < cap - 1 ? (size_t)n : cap - 1;
+  memcpy(dst, c->p + c->off, m);
+  dst[m] = 0;
+  c->off += (size_t)n;
+  return 0;
+}
+
+/* src/learner.cc LearnerIO::LoadModel(dmlc::Stream*) */
+static int parse_legacy(OBooster* b, const uint8_t* buf, size_t len) {
+  Cur c = {buf, len, 0};
+  if (len >= 4 && memcmp(buf, "binf", 4) == 0) c.off = 4;
+  /* LearnerModelParamLegacy: 136 bytes */
+  struct {
+    float base_score;
+    uint32_t num_feature;
+    int32_t num_class, contain_extra_attrs, contain_eval_metrics;
+    uint32_t major_version, minor_version, num_target;
+    int32_t reserved[26];
+  } mp;
+  if (sizeof mp != 136) return fail("oracle: LearnerModelParamLegacy is not 136 bytes");
+  if (take(&c, &mp, sizeof mp)) return fail("oracle: model file truncated (learner param)");
+  char booster_name[64];
+  if (take_string(&c, b->objective, sizeof b->objective)) return fail("oracle: bad objective string");
+  if (take_string(&c, booster_name, sizeof booster_name)) return fail("oracle: bad booster string");
+  if (strcmp(booster_name, "gbtree") != 0) return fail("oracle: only gbtree is restated");
+  /* GBTreeModelParam: 160 bytes, first field num_trees, size_leaf_vector at byte 28 */
+  uint8_t gp[160];
+  if (take(&c, gp, sizeof gp)) return fail("oracle: model file truncated (gbtree param)");
+  int32_t num_trees;
+  memcpy(&num_trees, gp, 4);
+  if (num_trees < 0 || num_trees > (1 << 24)) return fail("oracle: bad num_trees");
+  b->base_score = mp.base_score;
+  b->num_feature = mp.num_feature;
+  b->trees = (OTree*)calloc((size_t)(num_trees > 0 ? num_trees : 1), sizeof(OTree));
+  b->num_trees = num_trees;
+  for (int32_t t = 0; t < num_trees; ++t) {
+    /* TreeParam: 148 bytes; num_nodes is the second int */
+    int32_t tp[37];
+    if (take(&c, tp, sizeof tp)) return fail("oracle: model file truncated (tree param)");
+    int32_t n = tp[1];
+    if (n <= 0) return fail("oracle: tree without nodes");
+    if (tp[5] != 0) return fail("oracle: vector leaves are not restated");
+    b->trees[t].num_nodes = n;
+    b->trees[t].nodes = (RawNode*)malloc((size_t)n * sizeof(RawNode));
+    if (take(&c, b->trees[t].nodes, (size_t)n * sizeof(RawNode))) return fail("oracle: model file truncated (nodes)");
+    if (take(&c, NULL, (size_t)n * 16)) return fail("oracle: model file truncated (node stats)");
+  }
+  for (int32_t t = 0; t < num_trees; ++t) {
+    int32_t group;
+    if (take(&c, &group, 4)) return fail("oracle: model file truncated (tree_info)");
+    if (group != 0) return fail("oracle: multi-group boosters are not restated");
+  }
+  /* attributes / metric names follow; prediction does not need them */
+  b->loaded = 1;
+  return 0;
+}
+
+/* ---------------------------------------------------------------- prediction */
+
+static inline int is_missing(float v, float missing) { return isnan(v) || v == missing; }
+
+/* predict_fn.h GetNextNode + tree_model.h GetLeafIndex */
+static inline int32_t leaf_of(const OTree* t, const float* row, uint64_t ncol, uint32_t num_feature, float missing) {
+  int32_t nid = 0;
+  const RawNode* nd = t->nodes;
+  while (nd[nid].cleft != -1) {
+    const uint32_t split_index = nd[nid].sindex & 0x7FFFFFFFu;
+    /* FVec::Fill keeps only entries with index < num_feature; a column the
+       matrix does not have is missing as well */
+    int miss = 1;
+    float fvalue = 0.0f;
+    if (split_index < ncol && split_index < num_feature) {
+      fvalue = row[split_index];
+      miss = is_missing(fvalue, missing);
+    }
+    if (miss) {
+      nid = (nd[nid].sindex >> 31) ? nd[nid].cleft : nd[nid].cright;
+    } else {
+      nid = nd[nid].cleft + !(fvalue < nd[nid].info);
+    }
+  }
+  return nid;
+}
+
+static int predict_into(OBooster* b, const ODMatrix* d, int option_mask, unsigned ntree_limit, float* out) {
+  const uint32_t T = (uint32_t)b->num_trees;
+  const uint32_t tend = (ntree_limit == 0 || ntree_limit > T) ? T : ntree_limit;
+  const int pred_leaf = option_mask == 16;
+  const int64_t nblock = (int64_t)((d->nrow + 63) / 64);
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t blk = 0; blk < nblock; ++blk) {
+    const uint64_t r0 = (uint64_t)blk * 64;
+    const uint64_t r1 = r0 + 64 < d->nrow ? r0 + 64 : d->nrow;
+    if (!pred_leaf)
+      for (uint64_t r = r0; r < r1; ++r) out[r] = b->base_score; /* InitOutPredictions */
+    for (uint32_t t = 0; t < tend; ++t) {                         /* PredictByAllTrees: tree-major inside a block */
+      const OTree* tr = &b->trees[t];
+      for (uint64_t r = r0; r < r1; ++r) {
+        const int32_t leaf = leaf_of(tr, d->data + r * d->ncol, d->ncol, b->num_feature, d->missing);
+        if (pred_leaf) out[r * tend + t] = (float)leaf;
+        else out[r] += tr->nodes[leaf].info;
+      }
+    }
+  }
+  return 0;
+}
+
+/* ---------------------------------------------------------------- C ABI */
+
+ORACLE_EXPORT const char* XGBGetLastError(void) { return g_err; }
+
+ORACLE_EXPORT int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+ORACLE_EXPORT void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+ORACLE_EXPORT int XGDMatrixCreateFromMat(const float* data, bst_ulong nrow, bst_ulong ncol, float missing, void** out) {
+  if (!out) return fail("oracle: out is NULL");
+  const size_t count = (size_t)nrow * (size_t)ncol;
+  if (count && !data) return fail("oracle: data is NULL");
+  /* data.cc SparsePage::Push: valid = !(!isinf(missing) && isinf(value)) */
+  if (!isinf(missing))
+    for (size_t i = 0; i < count; ++i)
+      if (isinf(data[i])) return fail("Input data contains `inf` or `nan`");
+  ODMatrix* d = (ODMatrix*)calloc(1, sizeof *d);
+  d->magic = DMAT_MAGIC;
+  d->nrow = nrow;
+  d->ncol = ncol;
+  d->missing = missing;
+  d->data = (float*)malloc((count ? count : 1) * sizeof(float));
+  if (count) memcpy(d->data, data, count * sizeof(float));
+  *out = d;
+  return 0;
+}
+
+ORACLE_EXPORT int XGDMatrixFree(void* h) {
+  ODMatrix* d = (ODMatrix*)h;
+  if (!d || d->magic != DMAT_MAGIC) return fail("oracle: bad DMatrix handle");
+  d->magic = 0;
+  free(d->data);
+  free(d);
+  return 0;
+}
+
+ORACLE_EXPORT int XGDMatrixNumRow(void* h, bst_ulong* out) {
+  ODMatrix* d = (ODMatrix*)h;
+  if (!d || d->magic != DMAT_MAGIC || !out) return fail("oracle: bad DMatrix handle");
+  *out = d->nrow;
+  return 0;
+}
+
+ORACLE_EXPORT int XGDMatrixNumCol(void* h, bst_ulong* out) {
+  ODMatrix* d = (ODMatrix*)h;
+  if (!d || d->magic != DMAT_MAGIC || !out) return fail("oracle: bad DMatrix handle");
+  *out = d->ncol;
+  return 0;
+}
+
+ORACLE_EXPORT int XGDMatrixSaveBinary(void* h, const char* fname, int silent) {
+  (void)h; (void)fname; (void)silent;
+  return fail("oracle: XGDMatrixSaveBinary is outside the OH path and not restated");
+}
+
+ORACLE_EXPORT int XGDMatrixCreateFromFile(const char* fname, int silent, void** out) {
+  (void)fname; (void)silent; (void)out;
+  return fail("oracle: XGDMatrixCreateFromFile is outside the OH path and not restated");
+}
+
+ORACLE_EXPORT int XGBoosterCreate(const void* dmats, bst_ulong len, void** out) {
+  /* the reference passes a handle by value with len == 0 (OH_GridCompMod.F90:255-256) */
+  (void)dmats; (void)len;
+  if (!out) return fail("oracle: out is NULL");
+  OBooster* b = (OBooster*)calloc(1, sizeof *b);
+  b->magic = BOOSTER_MAGIC;
+  *out = b;
+  return 0;
+}
+
+ORACLE_EXPORT int XGBoosterFree(void* h) {
+  OBooster* b = (OBooster*)h;
+  if (!b || b->magic != BOOSTER_MAGIC) return fail("oracle: bad Booster handle");
+  free_trees(b);
+  free(b->pred);
+  b->magic = 0;
+  free(b);
+  return 0;
+}
+
+ORACLE_EXPORT int XGBoosterLoadModelFromBuffer(void* h, const void* buf, bst_ulong len) {
+  OBooster* b = (OBooster*)h;
+  if (!b || b->magic != BOOSTER_MAGIC) return fail("oracle: bad Booster handle");
+  if (!buf || len == 0) return fail("oracle: empty model buffer");
+  if (((const char*)buf)[0] == '{') return fail("oracle: JSON models are restated by oracle/xgb_oracle.py only");
+  free_trees(b);
+  if (parse_legacy(b, (const uint8_t*)buf, (size_t)len)) {
+    free_trees(b);
+    return -1;
+  }
+  return 0;
+}
+
+ORACLE_EXPORT int XGBoosterLoadModel(void* h, const char* fname) {
+  if (!fname) return fail("oracle: fname is NULL");
+  FILE* f = fopen(fname, "rb");
+  if (!f) return fail("oracle: cannot open model file");
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  uint8_t* buf = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
+  size_t got = fread(buf, 1, (size_t)n, f);
+  fclose(f);
+  int rc = (got == (size_t)n) ? XGBoosterLoadModelFromBuffer(h, buf, (bst_ulong)n) : fail("oracle: short read");
+  free(buf);
+  return rc;
+}
+
+ORACLE_EXPORT int XGBoosterSaveModel(void* h, const char* fname) {
+  (void)h; (void)fname;
+  return fail("oracle: XGBoosterSaveModel is outside the OH path and not restated");
+}
+
+ORACLE_EXPORT int XGBoosterPredict(void* h, void* dmat, int option_mask, unsigned ntree_limit, int training,
+                                   bst_ulong* out_len, const float** out_result) {
+  (void)training;
+  OBooster* b = (OBooster*)h;
+  ODMatrix* d = (ODMatrix*)dmat;
+  if (!b || b->magic != BOOSTER_MAGIC) return fail("oracle: bad Booster handle");
+  if (!d || d->magic != DMAT_MAGIC) return fail("oracle: bad DMatrix handle");
+  if (!b->loaded) return fail("oracle: no model loaded");
+  if (!out_len || !out_result) return fail("oracle: NULL output argument");
+  if (option_mask != 0 && option_mask != 1 && option_mask != 16) return fail("oracle: option_mask not restated");
+  if (option_mask == 0 && strcmp(b->objective, "reg:squarederror") != 0 && strcmp(b->objective, "reg:linear") != 0)
+    return fail("oracle: only identity objectives are restated");
+  if (d->ncol > b->num_feature) return fail("Number of columns does not match number of features in booster");
+  const uint32_t T = (uint32_t)b->num_trees;
+  const uint32_t tend = (ntree_limit == 0 || ntree_limit > T) ? T : ntree_limit;
+  const size_t count = (size_t)d->nrow * (option_mask == 16 ? tend : 1);
+  if (count > b->pred_cap) {
+    free(b->pred);
+    b->pred = (float*)malloc((count ? count : 1) * sizeof(float));
+    b->pred_cap = count;
+  }
+  predict_into(b, d, option_mask, ntree_limit, b->pred);
+  *out_len = count;
+  *out_result = b->pred;
+  return 0;
+}
+
+/*
+ * The RUN section of predict_OH_with_XGB, restated line by line
+ * (OH_GridCompMod.F90:275-383).  Arrays are Fortran order, 0-based here:
+ * 3-D fields (im,jm,km) index i + im*(j + jm*k); 2-D fields (im,jm).
+ * fields[] in the order of :313-339; is2d marks LAT, GMISTRATO3, ALBUV, SZA.
+ *   pl, tropp        the model's own PL_MOD (Pa) and TROPP (Pa) used for the slab (:275-298)
+ *   oh_ml            (im,jm,km), only k1..k2 written: 10.0**xx_pred (:369)
+ *   margin           optional, N raw predictions in row order
+ *   k1_out, k2_out   1-based slab bounds (:300-301)
+ * returns 0, or -1 with the message the reference would assert on.
+ */
+ORACLE_EXPORT int oracle_predict_OH_with_XGB(void* booster, int im, int jm, int km, int dynamic_k_range,
+                                             float tropp_min, const float* pl, const float* tropp,
+                                             const float* const fields[27], const int32_t is2d[27], float* oh_ml,
+                                             float* margin, int* k1_out, int* k2_out) {
+  const float xx_miss = -999.0f; /* :213 */
+  const int nparam = 27;         /* :228 */
+  const size_t plane = (size_t)im * (size_t)jm;
+  int ksubcount = 0;
+  if (!dynamic_k_range) { /* :287-288 */
+    size_t bad = 0;
+    for (size_t c = 0; c < plane; ++c) bad += (tropp[c] <= tropp_min);
+    if (bad) return fail("OH Prediction: Minimum tropopause pressure is not low enough!");
+  }
+  for (int j = 0; j < jm; ++j)
+    for (int i = 0; i < im; ++i) { /* :279-284 / :292-297 */
+      const float lim = dynamic_k_range ? tropp[i + (size_t)im * j] : tropp_min;
+      int k = 0;
+      for (int kk = 0; kk < km; ++kk) k += (pl[i + (size_t)im * (j + (size_t)jm * kk)] > lim);
+      if (k > ksubcount) ksubcount = k;
+    }
+  const int k1 = km - ksubcount + 1, k2 = km; /* 1-based, :300-301 */
+  if (k1_out) *k1_out = k1;
+  if (k2_out) *k2_out = k2;
+  const size_t n = plane * (size_t)ksubcount; /* :305 */
+  float* xx_carr = (float*)malloc((n ? n : 1) * (size_t)nparam * sizeof(float));
+  size_t m = 0;
+  for (int k = k1 - 1; k <= k2 - 1; ++k) /* :309-345 */
+    for (int j = 0; j < jm; ++j)
+      for (int i = 0; i < im; ++i) {
+        const size_t c2 = i + (size_t)im * j, c3 = c2 + plane * (size_t)k;
+        for (int f = 0; f < nparam; ++f) {
+          float v = is2d[f] ? fields[f][c2] : fields[f][c3];
+          if (f == 1) v = v / 100.0f; /* :314 Pa -> hPa */
+          xx_carr[m * (size_t)nparam + f] = v;
+        }
+        ++m;
+      }
+  void* dmat = NULL;
+  if (XGDMatrixCreateFromMat(xx_carr, n, (bst_ulong)nparam, xx_miss, &dmat)) { /* :347 */
+    free(xx_carr);
+    return -1;
+  }
+  bst_ulong len = 0;
+  const float* pred = NULL;
+  if (XGBoosterPredict(booster, dmat, 0, 0, 0, &len, &pred)) { /* :356, flags :231-235 */
+    XGDMatrixFree(dmat);
+    free(xx_carr);
+    return -1;
+  }
+  if (len != n) { /* :359 */
+    XGDMatrixFree(dmat);
+    free(xx_carr);
+    return fail("Wrong value returned for xx_pred_len");
+  }
+  m = 0;
+  for (int k = k1 - 1; k <= k2 - 1; ++k) /* :364-374 */
+    for (size_t c2 = 0; c2 < plane; ++c2) {
+      oh_ml[c2 + plane * (size_t)k] = powf(10.0f, pred[m]); /* 10.0 ** xx_pred(m), real(4) */
+      if (margin) margin[m] = pred[m];
+      ++m;
+    }
+  XGDMatrixFree(dmat); /* :377 */
+  free(xx_carr);       /* :383 */
+  return 0;
+}
+
+ORACLE_EXPORT int XGBoosterSetParam(void* h, const char* name, const char* value) {
+  (void)h; (void)name; (void)value;
+  return 0;
+}
+
+/*
+ * CPU restatement of the product's fused entry point (include/ohxgb.h
+ * OHXBoosterPredictFields), so the Fortran mock driver links against the oracle
+ * as well: the same gather / PL/100 / predict / 10** steps as above, then
+ * "* ohscale" (OH_GridCompMod.F90:1569), for a slab the caller has chosen.
+ */
+ORACLE_EXPORT int OHXBoosterPredictFields(void* booster, const float* const fields[], const int32_t is2d[], int nfield,
+                                          int pl_feature, int im, int jm, int km, int k1, int k2, float missing,
+                                          int apply_pow10, float ohscale, float* oh_ml, float* margin) {
+  (void)km;
+  const size_t plane = (size_t)im * (size_t)jm;
+  if (k2 < k1) return 0;
+  const size_t n = plane * (size_t)(k2 - k1 + 1);
+  float* xx_carr = (float*)malloc(n * (size_t)nfield * sizeof(float));
+  size_t m = 0;
+  for (int k = k1 - 1; k <= k2 - 1; ++k)
+    for (size_t c2 = 0; c2 < plane; ++c2) {
+      for (int f = 0; f < nfield; ++f) {
+        float v = is2d[f] ? fields[f][c2] : fields[f][c2 + plane * (size_t)k];
+        if (f == pl_feature) v = v / 100.0f;
+        xx_carr[m * (size_t)nfield + f] = v;
+      }
+      ++m;
+    }
+  void* dmat = NULL;
+  int rc = XGDMatrixCreateFromMat(xx_carr, n, (bst_ulong)nfield, missing, &dmat);
+  bst_ulong len = 0;
+  const float* pred = NULL;
+  if (rc == 0) rc = XGBoosterPredict(booster, dmat, 0, 0, 0, &len, &pred);
+  if (rc == 0) {
+    m = 0;
+    for (int k = k1 - 1; k <= k2 - 1; ++k)
+      for (size_t c2 = 0; c2 < plane; ++c2) {
+        float v = apply_pow10 ? powf(10.0f, pred[m]) : pred[m];
+        oh_ml[c2 + plane * (size_t)k] = v * ohscale;
+        if (margin) margin[m] = pred[m];
+        ++m;
+      }
+  }
+  if (dmat) XGDMatrixFree(dmat);
+  free(xx_carr);
+  return rc;
+}

@@ -1,0 +1,235 @@
+"""numpy restatement of the OH XGBoost-predict path.  TEST INFRASTRUCTURE.
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may
+import this; the product never does.
+
+PARITY UNPINNED: the reference (GEOS-ESM/QuickChem @ 2024-11-08) has no tests,
+golden vectors or model files for this path and delegates the arithmetic to
+xgboost 1.6.0 (reference ``Shared/CMakeLists.txt:8``), which is not vendored and
+not installable here.  This module restates the published xgboost 1.6.0
+semantics independently of ``oracle/xgb_oracle.c`` (different language, level
+synchronous instead of row-at-a-time, its own file parsers) so that the two can
+be checked against each other bit for bit, and against the hand-computed vectors
+in ``tests/golden/``.
+
+Restated pieces, with the upstream file each follows:
+  * legacy binary model layout   - xgboost src/learner.cc, src/gbm/gbtree_model.cc,
+                                   src/tree/tree_model.cc
+  * JSON model layout            - xgboost doc/model.schema (1.6.0)
+  * dense matrix semantics       - src/data/adapter.h + src/data/data.cc: an entry
+                                   is missing iff NaN or == ``missing``; +-inf is an
+                                   error unless ``missing`` is inf
+  * prediction                   - src/predictor/cpu_predictor.cc +
+                                   src/predictor/predict_fn.h:
+                                   pred = base_score; for each tree in order
+                                   pred += leaf; step = default child if missing
+                                   else ``cleft + !(fvalue < split_cond)``
+  * predict_OH_with_XGB RUN part - reference OH_GridComp/OH_GridCompMod.F90:275-383
+"""
+from __future__ import annotations
+
+import json
+import struct
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+NODE_DTYPE = np.dtype([("parent", "<i4"), ("cleft", "<i4"), ("cright", "<i4"),
+                       ("sindex", "<u4"), ("info", "<f4")])
+assert NODE_DTYPE.itemsize == 20
+
+FEATURE_NAMES = ["LAT", "PL", "T", "NO2", "O3", "CH4", "CO", "ISOP", "ACET", "C2H6", "C3H8",
+                 "PRPE", "ALK4", "MP", "H2O2", "TAUCLWDN", "TAUCLIDN", "TAUCLIUP", "TAUCLWUP",
+                 "CLOUD", "QV", "GMISTRATO3", "ALBUV", "AODUP", "AODDN", "CH2O", "SZA"]
+IS2D = [n in ("LAT", "GMISTRATO3", "ALBUV", "SZA") for n in FEATURE_NAMES]
+XX_MISS = np.float32(-999.0)          # OH_GridCompMod.F90:213
+
+
+@dataclass
+class OracleTree:
+    cleft: np.ndarray      # int32, -1 => leaf
+    cright: np.ndarray     # int32
+    feature: np.ndarray    # uint32
+    default_left: np.ndarray  # bool
+    value: np.ndarray      # float32: split_cond or leaf value
+
+
+@dataclass
+class OracleModel:
+    base_score: np.float32
+    num_feature: int
+    objective: str
+    trees: List[OracleTree] = field(default_factory=list)
+
+    @property
+    def total_nodes(self) -> int:
+        return int(sum(len(t.cleft) for t in self.trees))
+
+
+# --------------------------------------------------------------------- loaders
+
+def _read_str(buf: bytes, off: int) -> Tuple[str, int]:
+    (n,) = struct.unpack_from("<Q", buf, off)
+    off += 8
+    return buf[off:off + n].decode("utf-8", "replace"), off + n
+
+
+def load_legacy_binary(buf: bytes) -> OracleModel:
+    off = 4 if buf[:4] == b"binf" else 0
+    base_score, num_feature, _num_class, _extra, _metrics, _maj, _min, _ntarget = struct.unpack_from(
+        "<fIiiiIII", buf, off)
+    off += 136
+    objective, off = _read_str(buf, off)
+    booster, off = _read_str(buf, off)
+    if booster != "gbtree":
+        raise ValueError("oracle: only gbtree is restated")
+    (num_trees,) = struct.unpack_from("<i", buf, off)
+    off += 160
+    model = OracleModel(np.float32(base_score), int(num_feature), objective)
+    for _ in range(num_trees):
+        tp = struct.unpack_from("<37i", buf, off)
+        off += 148
+        n = tp[1]
+        nodes = np.frombuffer(buf, dtype=NODE_DTYPE, count=n, offset=off)
+        off += 20 * n + 16 * n
+        sindex = nodes["sindex"]
+        model.trees.append(OracleTree(
+            cleft=nodes["cleft"].astype(np.int32),
+            cright=nodes["cright"].astype(np.int32),
+            feature=(sindex & np.uint32(0x7FFFFFFF)).astype(np.uint32),
+            default_left=(sindex >> np.uint32(31)).astype(bool),
+            value=nodes["info"].astype(np.float32)))
+    info = np.frombuffer(buf, dtype="<i4", count=num_trees, offset=off)
+    if np.any(info != 0):
+        raise ValueError("oracle: multi-group boosters are not restated")
+    return model
+
+
+def load_json(text) -> OracleModel:
+    if isinstance(text, (bytes, bytearray)):
+        text = bytes(text).rstrip(b"\0").decode("utf-8")
+    doc = json.loads(text)
+    learner = doc["learner"]
+    lmp = learner["learner_model_param"]
+    gb = learner["gradient_booster"]
+    if gb["name"] != "gbtree":
+        raise ValueError("oracle: only gbtree is restated")
+    model = OracleModel(np.float32(float(lmp["base_score"])), int(lmp["num_feature"]),
+                        learner["objective"]["name"])
+    for jt in gb["model"]["trees"]:
+        model.trees.append(OracleTree(
+            cleft=np.asarray(jt["left_children"], dtype=np.int32),
+            cright=np.asarray(jt["right_children"], dtype=np.int32),
+            feature=np.asarray(jt["split_indices"], dtype=np.uint32),
+            default_left=np.asarray(jt["default_left"]).astype(bool),
+            value=np.asarray(jt["split_conditions"], dtype=np.float64).astype(np.float32)))
+    if any(g != 0 for g in gb["model"]["tree_info"]):
+        raise ValueError("oracle: multi-group boosters are not restated")
+    return model
+
+
+def load_model(buf: bytes) -> OracleModel:
+    return load_json(buf) if buf[:1] == b"{" else load_legacy_binary(buf)
+
+
+# --------------------------------------------------------------------- prediction
+
+def check_dense(data: np.ndarray, missing) -> None:
+    """data.cc SparsePage::Push: inf is refused unless `missing` is inf."""
+    if not np.isinf(np.float32(missing)) and np.isinf(data).any():
+        raise ValueError("Input data contains `inf` or `nan`")
+
+
+def leaf_indices(tree: OracleTree, rows: np.ndarray, missing, num_feature: int) -> np.ndarray:
+    """Level-synchronous walk of one tree for all rows; returns the leaf node ids."""
+    n, ncol = rows.shape
+    nid = np.zeros(n, dtype=np.int64)
+    active = np.nonzero(tree.cleft[nid] != -1)[0]
+    missing = np.float32(missing)
+    while active.size:
+        cur = nid[active]
+        f = tree.feature[cur].astype(np.int64)
+        have = (f < ncol) & (f < num_feature)
+        fv = np.zeros(active.size, dtype=np.float32)
+        fv[have] = rows[active[have], f[have]]
+        miss = ~have | np.isnan(fv) | (fv == missing)
+        step_default = np.where(tree.default_left[cur], tree.cleft[cur], tree.cright[cur])
+        with np.errstate(invalid="ignore"):
+            step_value = tree.cleft[cur] + (~(fv < tree.value[cur])).astype(np.int32)
+        nxt = np.where(miss, step_default, step_value)
+        nid[active] = nxt
+        active = active[tree.cleft[nxt] != -1]
+    return nid
+
+
+def predict(model: OracleModel, rows: np.ndarray, missing=np.nan, ntree_limit: int = 0,
+            pred_leaf: bool = False) -> np.ndarray:
+    """XGBoosterPredict(option_mask in {0,1} or 16, ntree_limit) on a dense float32 matrix."""
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    if rows.ndim != 2:
+        raise ValueError("rows must be 2-D")
+    if rows.shape[1] > model.num_feature:
+        raise ValueError("Number of columns does not match number of features in booster")
+    check_dense(rows, missing)
+    T = len(model.trees)
+    tend = T if ntree_limit == 0 or ntree_limit > T else ntree_limit
+    if pred_leaf:
+        out = np.empty((rows.shape[0], tend), dtype=np.float32)
+        for t in range(tend):
+            out[:, t] = leaf_indices(model.trees[t], rows, missing, model.num_feature)
+        return out
+    acc = np.full(rows.shape[0], model.base_score, dtype=np.float32)
+    for t in range(tend):                      # tree order matters: float32 adds do not commute
+        leaf = leaf_indices(model.trees[t], rows, missing, model.num_feature)
+        acc = (acc + model.trees[t].value[leaf]).astype(np.float32)
+    return acc
+
+
+# --------------------------------------------------------------------- the Fortran caller
+
+def k_slab(pl: np.ndarray, tropp: np.ndarray, dynamic_k_range: bool, tropp_min: float) -> Tuple[int, int]:
+    """OH_GridCompMod.F90:275-301.  pl is (im,jm,km) [i,j,k], tropp (im,jm); returns 1-based (k1,k2)."""
+    km = pl.shape[2]
+    if dynamic_k_range:
+        counts = (pl > tropp[:, :, None]).sum(axis=2)
+    else:
+        if np.count_nonzero(tropp <= np.float32(tropp_min)):
+            raise AssertionError("OH Prediction: Minimum tropopause pressure is not low enough!")
+        counts = (pl > np.float32(tropp_min)).sum(axis=2)
+    ksub = int(counts.max()) if counts.size else 0
+    return km - ksub + 1, km
+
+
+def gather_rows(fields: Sequence[np.ndarray], k1: int, k2: int) -> np.ndarray:
+    """OH_GridCompMod.F90:303-345: xx_carr(27, N) as a C [N][27] array; i fastest, then j, then k."""
+    im, jm = fields[1].shape[:2]
+    nlev = k2 - k1 + 1
+    out = np.empty((nlev, jm, im, len(fields)), dtype=np.float32)
+    for f, a in enumerate(fields):
+        if a.ndim == 2:
+            out[..., f] = a.T[None, :, :]
+        else:
+            sl = a[:, :, k1 - 1:k2]
+            if f == 1:
+                sl = (sl / np.float32(100.0)).astype(np.float32)      # :314
+            out[..., f] = np.transpose(sl, (2, 1, 0))
+    return out.reshape(nlev * jm * im, len(fields))
+
+
+def predict_OH_with_XGB(model: OracleModel, pl: np.ndarray, tropp: np.ndarray, fields: Sequence[np.ndarray],
+                        dynamic_k_range: bool, tropp_min: float = 4000.0,
+                        oh_ml: Optional[np.ndarray] = None):
+    """RUN section of predict_OH_with_XGB (OH_GridCompMod.F90:275-383).
+
+    Arrays are indexed [i,j,k] like the Fortran ones.  Returns (oh_ml, margin, k1, k2)."""
+    im, jm, km = pl.shape
+    k1, k2 = k_slab(pl, tropp, dynamic_k_range, tropp_min)
+    rows = gather_rows(fields, k1, k2)
+    margin = predict(model, rows, missing=XX_MISS)
+    if oh_ml is None:
+        oh_ml = np.zeros((im, jm, km), dtype=np.float32)               # :1559
+    nlev = k2 - k1 + 1
+    oh = np.power(np.float32(10.0), margin, dtype=np.float32)          # :369
+    oh_ml[:, :, k1 - 1:k2] = np.transpose(oh.reshape(nlev, jm, im), (2, 1, 0))
+    return oh_ml, margin, k1, k2

@@ -1,0 +1,244 @@
+"""ctypes binding of libohxgb.so (include/ohxgb.h) — plumbing only.
+
+The names mirror the reference's Fortran binding module
+(``Shared/xgb_fortran_api.F90``): the same eleven XGBoost C-API symbols, plus the
+device-resident / fused extensions.  Nothing here computes; every numeric result
+comes out of the HIP kernels in the shared library, and loading fails loudly if
+the library has not been built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libohxgb.so")
+
+# every symbol include/ohxgb.h declares
+ABI_SYMBOLS = [
+    "XGBGetLastError", "XGDMatrixCreateFromMat", "XGDMatrixFree", "XGDMatrixNumRow", "XGDMatrixNumCol",
+    "XGDMatrixSaveBinary", "XGDMatrixCreateFromFile", "XGBoosterCreate", "XGBoosterFree", "XGBoosterLoadModel",
+    "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
+    "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXBoosterPredictDevice", "OHXBoosterCheck",
+    "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterGetInfo", "OHXSynthRowsDevice",
+    "OHXSynthFieldDevice", "OHXInjectMissingDevice",
+]
+# the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
+REFERENCE_BOUND_SYMBOLS = [
+    "XGBoosterLoadModel", "XGBoosterSaveModel", "XGDMatrixSaveBinary", "XGDMatrixFree", "XGDMatrixCreateFromFile",
+    "XGBoosterPredict", "XGBoosterCreate", "XGDMatrixCreateFromMat", "XGDMatrixNumRow", "XGDMatrixNumCol",
+    "XGBoosterFree",
+]
+
+
+class OhxError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def declare_xgb_api(lib: C.CDLL) -> C.CDLL:
+    """Attach argtypes for the XGBoost C-API subset (shared with the CPU oracle library)."""
+    vp, u64, f32, i32 = C.c_void_p, C.c_uint64, C.c_float, C.c_int
+    lib.XGBGetLastError.restype = C.c_char_p
+    lib.XGBGetLastError.argtypes = []
+    lib.XGDMatrixCreateFromMat.argtypes = [vp, u64, u64, f32, C.POINTER(vp)]
+    lib.XGDMatrixFree.argtypes = [vp]
+    lib.XGDMatrixNumRow.argtypes = [vp, C.POINTER(u64)]
+    lib.XGDMatrixNumCol.argtypes = [vp, C.POINTER(u64)]
+    lib.XGDMatrixSaveBinary.argtypes = [vp, C.c_char_p, i32]
+    lib.XGDMatrixCreateFromFile.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    lib.XGBoosterCreate.argtypes = [vp, u64, C.POINTER(vp)]
+    lib.XGBoosterFree.argtypes = [vp]
+    lib.XGBoosterLoadModel.argtypes = [vp, C.c_char_p]
+    lib.XGBoosterSaveModel.argtypes = [vp, C.c_char_p]
+    lib.XGBoosterLoadModelFromBuffer.argtypes = [vp, vp, u64]
+    lib.XGBoosterPredict.argtypes = [vp, vp, i32, C.c_uint, i32, C.POINTER(u64), C.POINTER(C.POINTER(f32))]
+    return lib
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    global _lib
+    if _lib is not None and path == LIB_PATH:
+        return _lib
+    if not os.path.exists(path):
+        raise OhxError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    lib = declare_xgb_api(C.CDLL(path))
+    vp, u64, f32, i32, u32 = C.c_void_p, C.c_uint64, C.c_float, C.c_int, C.c_uint32
+    lib.XGBoosterSetParam.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.OHXDeviceCount.argtypes = [C.POINTER(i32)]
+    lib.OHXDMatrixCreateFromDevice.argtypes = [vp, u64, u64, f32, C.POINTER(vp)]
+    lib.OHXBoosterPredictDevice.argtypes = [vp, vp, i32, C.c_uint, vp, vp]
+    lib.OHXBoosterCheck.argtypes = [vp, vp]
+    lib.OHXBoosterPredictFields.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), i32, i32, i32, i32, i32, i32, i32,
+                                            f32, i32, f32, vp, vp]
+    lib.OHXBoosterPredictFieldsDevice.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), i32, i32, i32, i32, i32,
+                                                  i32, i32, f32, i32, f32, vp, vp, vp]
+    lib.OHXBoosterGetInfo.argtypes = [vp, C.POINTER(u64)]
+    lib.OHXSynthRowsDevice.argtypes = [u32, i32, i32, i32, u64, u64, vp, vp]
+    lib.OHXSynthFieldDevice.argtypes = [u32, i32, i32, i32, i32, vp, vp]
+    lib.OHXInjectMissingDevice.argtypes = [vp, u64, u32, u32, f32, vp]
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def check(lib: C.CDLL, rc: int) -> None:
+    if rc != 0:
+        raise OhxError(lib.XGBGetLastError().decode("utf-8", "replace"))
+
+
+def _as_f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class DMatrix:
+    """XGDMatrixCreateFromMat / OHXDMatrixCreateFromDevice handle."""
+
+    def __init__(self, data=None, missing: float = float("nan"), *, device_ptr: int = 0, nrow: int = 0, ncol: int = 0,
+                 lib: Optional[C.CDLL] = None):
+        self.lib = lib or load_library()
+        self.handle = C.c_void_p()
+        if data is not None:
+            arr = _as_f32(data)
+            if arr.ndim != 2:
+                raise ValueError("data must be 2-D [nrow][ncol]")
+            nrow, ncol = arr.shape
+            check(self.lib, self.lib.XGDMatrixCreateFromMat(arr.ctypes.data, nrow, ncol, missing, C.byref(self.handle)))
+        else:
+            check(self.lib, self.lib.OHXDMatrixCreateFromDevice(device_ptr, nrow, ncol, missing, C.byref(self.handle)))
+
+    @property
+    def num_row(self) -> int:
+        out = C.c_uint64()
+        check(self.lib, self.lib.XGDMatrixNumRow(self.handle, C.byref(out)))
+        return out.value
+
+    @property
+    def num_col(self) -> int:
+        out = C.c_uint64()
+        check(self.lib, self.lib.XGDMatrixNumCol(self.handle, C.byref(out)))
+        return out.value
+
+    def save_binary(self, fname: str) -> None:
+        check(self.lib, self.lib.XGDMatrixSaveBinary(self.handle, fname.encode(), 1))
+
+    @classmethod
+    def from_file(cls, fname: str, lib: Optional[C.CDLL] = None) -> "DMatrix":
+        self = cls.__new__(cls)
+        self.lib = lib or load_library()
+        self.handle = C.c_void_p()
+        check(self.lib, self.lib.XGDMatrixCreateFromFile(fname.encode(), 1, C.byref(self.handle)))
+        return self
+
+    def free(self) -> None:
+        if self.handle:
+            check(self.lib, self.lib.XGDMatrixFree(self.handle))
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Booster:
+    """XGBoosterCreate / LoadModel / Predict handle."""
+
+    def __init__(self, model_file: Optional[str] = None, *, model_buffer: Optional[bytes] = None,
+                 lib: Optional[C.CDLL] = None):
+        self.lib = lib or load_library()
+        self.handle = C.c_void_p()
+        # as the reference does: a handle by value and len == 0 (OH_GridCompMod.F90:255-256)
+        check(self.lib, self.lib.XGBoosterCreate(None, 0, C.byref(self.handle)))
+        if model_file is not None:
+            self.load_model(model_file)
+        elif model_buffer is not None:
+            self.load_model_buffer(model_buffer)
+
+    def load_model(self, fname: str) -> None:
+        check(self.lib, self.lib.XGBoosterLoadModel(self.handle, fname.encode()))
+
+    def load_model_buffer(self, buf) -> None:
+        if isinstance(buf, np.ndarray):
+            ptr, n = buf.ctypes.data, buf.nbytes
+            check(self.lib, self.lib.XGBoosterLoadModelFromBuffer(self.handle, ptr, n))
+        else:
+            b = bytes(buf)
+            check(self.lib, self.lib.XGBoosterLoadModelFromBuffer(self.handle, C.cast(C.c_char_p(b), C.c_void_p), len(b)))
+
+    def save_model(self, fname: str) -> None:
+        check(self.lib, self.lib.XGBoosterSaveModel(self.handle, fname.encode()))
+
+    def set_param(self, name: str, value) -> None:
+        check(self.lib, self.lib.XGBoosterSetParam(self.handle, name.encode(), str(value).encode()))
+
+    def predict(self, dmat: DMatrix, option_mask: int = 0, ntree_limit: int = 0, training: int = 0) -> np.ndarray:
+        """Host result (copy of the booster-owned buffer), float32."""
+        n = C.c_uint64()
+        ptr = C.POINTER(C.c_float)()
+        check(self.lib, self.lib.XGBoosterPredict(self.handle, dmat.handle, option_mask, ntree_limit, training,
+                                                   C.byref(n), C.byref(ptr)))
+        if n.value == 0:
+            return np.empty(0, dtype=np.float32)
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+    def predict_device(self, dmat: DMatrix, out_ptr: int, option_mask: int = 0, ntree_limit: int = 0,
+                       stream: int = 0) -> None:
+        check(self.lib, self.lib.OHXBoosterPredictDevice(self.handle, dmat.handle, option_mask, ntree_limit, out_ptr,
+                                                          stream))
+
+    def check(self, stream: int = 0) -> None:
+        check(self.lib, self.lib.OHXBoosterCheck(self.handle, stream))
+
+    def predict_fields(self, fields: Sequence[np.ndarray], is2d: Sequence[bool], pl_feature: int, im: int, jm: int,
+                       km: int, k1: int, k2: int, missing: float, oh_ml: np.ndarray, *, apply_pow10: bool = True,
+                       ohscale: float = 1.0, margin: Optional[np.ndarray] = None) -> None:
+        """Host arrays in Fortran order (pass the .T views' buffers: index i + im*(j + jm*k))."""
+        nf = len(fields)
+        ptrs = (C.c_void_p * nf)(*[f.ctypes.data for f in fields])
+        flags = (C.c_int32 * nf)(*[1 if b else 0 for b in is2d])
+        check(self.lib, self.lib.OHXBoosterPredictFields(
+            self.handle, ptrs, flags, nf, pl_feature, im, jm, km, k1, k2, missing, 1 if apply_pow10 else 0, ohscale,
+            oh_ml.ctypes.data, margin.ctypes.data if margin is not None else None))
+
+    def predict_fields_device(self, field_ptrs: Sequence[int], is2d: Sequence[bool], pl_feature: int, im: int,
+                              jm: int, km: int, k1: int, k2: int, missing: float, oh_ml_ptr: int, *,
+                              apply_pow10: bool = True, ohscale: float = 1.0, margin_ptr: int = 0,
+                              stream: int = 0) -> None:
+        nf = len(field_ptrs)
+        ptrs = (C.c_void_p * nf)(*field_ptrs)
+        flags = (C.c_int32 * nf)(*[1 if b else 0 for b in is2d])
+        check(self.lib, self.lib.OHXBoosterPredictFieldsDevice(
+            self.handle, ptrs, flags, nf, pl_feature, im, jm, km, k1, k2, missing, 1 if apply_pow10 else 0, ohscale,
+            oh_ml_ptr, margin_ptr or None, stream or None))
+
+    def info(self) -> dict:
+        arr = (C.c_uint64 * 8)()
+        check(self.lib, self.lib.OHXBoosterGetInfo(self.handle, arr))
+        keys = ["num_trees", "num_nodes", "num_slots", "node_bytes", "max_depth", "num_feature", "packed"]
+        return {k: int(arr[i]) for i, k in enumerate(keys)}
+
+    def free(self) -> None:
+        if self.handle:
+            check(self.lib, self.lib.XGBoosterFree(self.handle))
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int()
+    check(lib, lib.OHXDeviceCount(C.byref(n)))
+    return n.value

@@ -1,0 +1,719 @@
+// C ABI of libohxgb.so (include/ohxgb.h): the XGBoost C-API symbols that
+// QuickChem's Shared/xgb_fortran_api.F90 binds, served by the gfx950 kernels,
+// plus the device-resident and fused entry points.
+//
+// Host logic only: handle bookkeeping, model load/save, lazy upload of the
+// flattened booster to HBM, staging and launches.  No prediction arithmetic
+// happens on the CPU anywhere in this library.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/ohxgb.h"
+#include "flatten.hpp"
+#include "forest.hpp"
+#include "kernels.hpp"
+
+using namespace ohx;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+void set_error(const std::string& m) { g_last_error = m; }
+
+#define API_BEGIN() try {
+#define API_END()                                   \
+  }                                                 \
+  catch (const std::exception& e) {                 \
+    set_error(e.what());                            \
+    return -1;                                      \
+  }                                                 \
+  catch (...) {                                     \
+    set_error("unknown error");                     \
+    return -1;                                      \
+  }                                                 \
+  return 0;
+
+#define HIP_CHECK(expr)                                                                            \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) throw OhxError(std::string(#expr) + " failed: " + hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr uint32_t kDMatMagic = 0x4F48444Du;   // "OHDM"
+constexpr uint32_t kBoosterMagic = 0x4F484253u; // "OHBS"
+
+// ------------------------------------------------------------------ device
+
+struct DeviceInfo {
+  int ordinal = -1;
+  int num_cus = 0;
+};
+
+int device_count_or_throw() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw OhxError(std::string("libohxgb needs a HIP device and has no CPU fallback: hipGetDeviceCount: ") +
+                   (e != hipSuccess ? hipGetErrorString(e) : "0 devices"));
+  return n;
+}
+
+DeviceInfo use_device(int ordinal) {
+  const int n = device_count_or_throw();
+  if (ordinal < 0) {
+    int cur = 0;
+    HIP_CHECK(hipGetDevice(&cur));
+    ordinal = cur;
+  }
+  if (ordinal >= n) throw OhxError("HIP device ordinal " + std::to_string(ordinal) + " out of range");
+  HIP_CHECK(hipSetDevice(ordinal));
+  DeviceInfo d;
+  d.ordinal = ordinal;
+  int cus = 0;
+  HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
+  d.num_cus = cus > 0 ? cus : 256;
+  return d;
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void ensure(size_t count) {
+    if (count <= n) return;
+    release();
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    n = count;
+  }
+  void upload(const std::vector<T>& h) {
+    ensure(h.size());
+    if (!h.empty()) HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+};
+
+template <class T>
+struct PinnedBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~PinnedBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  void ensure(size_t count) {
+    if (count <= n) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault));
+    n = count;
+  }
+};
+
+// ------------------------------------------------------------------ objects
+
+struct DMatrixObj {
+  uint32_t magic = kDMatMagic;
+  uint64_t nrow = 0, ncol = 0;
+  float missing = NAN;
+  const float* d_data = nullptr;  // device
+  DevBuf<float> owned;            // set when the matrix owns its storage
+  int device = -1;
+};
+
+struct BoosterObj {
+  uint32_t magic = kBoosterMagic;
+  Forest forest;
+  bool loaded = false;
+  LayoutParams layout;
+  std::string kernel_name = "auto";
+  int device_pref = -1;
+  // device state, built lazily at the first compute call
+  bool uploaded = false;
+  DeviceInfo dev;
+  Placement placement;
+  bool packed_ok = false;
+  DevBuf<PackedNode> d_packed;
+  DevBuf<WideNode> d_wide;
+  DevBuf<uint32_t> d_roots;
+  DevBuf<uint32_t> d_flags;
+  DevBuf<float> d_pred;
+  PinnedBuf<float> h_pred;
+  std::vector<DevBuf<float>> d_stage;  // fused host path: per-field staging
+  DevBuf<float> d_stage_out, d_stage_margin;
+};
+
+DMatrixObj* as_dmat(DMatrixHandle h) {
+  auto* d = static_cast<DMatrixObj*>(h);
+  if (d == nullptr || d->magic != kDMatMagic) throw OhxError("DMatrix handle is invalid or has been freed");
+  return d;
+}
+
+BoosterObj* as_booster(BoosterHandle h) {
+  auto* b = static_cast<BoosterObj*>(h);
+  if (b == nullptr || b->magic != kBoosterMagic) throw OhxError("Booster handle is invalid or has been freed");
+  return b;
+}
+
+KernelKind pick_kernel(const BoosterObj& b) {
+  const std::string& k = b.kernel_name;
+  if (!b.packed_ok || k == "wide") return KernelKind::Wide;
+  if (k == "packed1") return KernelKind::Packed1;
+  if (k == "packed2") return KernelKind::Packed2;
+  return KernelKind::Packed4;
+}
+
+void invalidate_device_state(BoosterObj& b) {
+  b.uploaded = false;
+  b.d_packed.release();
+  b.d_wide.release();
+  b.d_roots.release();
+}
+
+void ensure_wide(BoosterObj& b) {
+  if (b.d_wide.p) return;
+  std::vector<WideNode> wide = emit_wide(b.forest, b.placement);
+  b.d_wide.upload(wide);
+}
+
+void ensure_uploaded(BoosterObj& b) {
+  if (!b.loaded) throw OhxError("the booster holds no model: call XGBoosterLoadModel first");
+  if (b.uploaded) {
+    HIP_CHECK(hipSetDevice(b.dev.ordinal));
+    return;
+  }
+  b.dev = use_device(b.device_pref);
+  b.placement = place_forest(b.forest, b.layout);
+  b.packed_ok = packed_format_fits(b.forest, b.placement);
+  b.d_roots.upload(b.placement.roots);
+  if (b.packed_ok) {
+    std::vector<PackedNode> packed = emit_packed(b.forest, b.placement, nullptr);
+    b.d_packed.upload(packed);
+  }
+  if (pick_kernel(b) == KernelKind::Wide) ensure_wide(b);
+  b.d_flags.ensure(1);
+  HIP_CHECK(hipMemset(b.d_flags.p, 0, sizeof(uint32_t)));
+  b.uploaded = true;
+}
+
+DeviceForest device_forest(const BoosterObj& b) {
+  DeviceForest d;
+  d.packed = b.d_packed.p;
+  d.wide = b.d_wide.p;
+  d.roots = b.d_roots.p;
+  d.num_trees = (uint32_t)b.forest.trees.size();
+  d.num_feature = b.forest.num_feature;
+  d.base_score = b.forest.base_score;
+  return d;
+}
+
+void tree_range(const BoosterObj& b, unsigned ntree_limit, uint32_t* t0, uint32_t* t1) {
+  const uint32_t T = (uint32_t)b.forest.trees.size();
+  *t0 = 0;
+  *t1 = (ntree_limit == 0 || ntree_limit > T) ? T : ntree_limit;
+}
+
+void check_predict_options(const BoosterObj& b, int option_mask, bool* pred_leaf) {
+  *pred_leaf = false;
+  if (option_mask == 0 || option_mask == 1) {
+    if (option_mask == 0 && !objective_is_identity(b.forest.objective))
+      throw OhxError("objective '" + b.forest.objective +
+                     "' needs a prediction transform this library does not implement; "
+                     "use option_mask = 1 (margin) or a reg:squarederror model");
+    return;
+  }
+  if (option_mask == 16) {
+    *pred_leaf = true;
+    return;
+  }
+  throw OhxError("XGBoosterPredict: option_mask " + std::to_string(option_mask) +
+                 " is not supported (0 = value, 1 = margin, 16 = leaf index)");
+}
+
+void check_columns(const BoosterObj& b, uint64_t ncol) {
+  if (ncol > b.forest.num_feature)
+    throw OhxError("Number of columns does not match number of features in booster (" + std::to_string(ncol) +
+                   " vs. " + std::to_string(b.forest.num_feature) + ")");
+}
+
+void raise_flag_errors(BoosterObj& b, hipStream_t stream) {
+  uint32_t flags = 0;
+  HIP_CHECK(hipMemcpyAsync(&flags, b.d_flags.p, sizeof(flags), hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  if (flags != 0) {
+    HIP_CHECK(hipMemsetAsync(b.d_flags.p, 0, sizeof(uint32_t), stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (flags & kFlagInfInput) throw OhxError("Input data contains `inf` or `nan`");
+    throw OhxError("the predict kernel reported error flags " + std::to_string(flags));
+  }
+}
+
+bool ends_with(const std::string& s, const std::string& suf) {
+  return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+void launch_predict_checked(BoosterObj& b, const DMatrixObj& d, int option_mask, unsigned ntree_limit, float* d_out,
+                            hipStream_t stream) {
+  bool pred_leaf = false;
+  check_predict_options(b, option_mask, &pred_leaf);
+  check_columns(b, d.ncol);
+  ensure_uploaded(b);
+  if (d.device >= 0 && d.device != b.dev.ordinal)
+    throw OhxError("the DMatrix lives on HIP device " + std::to_string(d.device) + " but the booster on device " +
+                   std::to_string(b.dev.ordinal));
+  KernelKind kind = pick_kernel(b);
+  if (pred_leaf || kind == KernelKind::Wide) ensure_wide(b);
+  PredictArgs a;
+  a.rows = d.d_data;
+  a.nrow = d.nrow;
+  a.ncol = (uint32_t)d.ncol;
+  a.missing = d.missing;
+  tree_range(b, ntree_limit, &a.tree_begin, &a.tree_end);
+  a.out = d_out;
+  a.pred_leaf = pred_leaf;
+  a.flags = b.d_flags.p;
+  HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream));
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* XGBGetLastError(void) { return g_last_error.c_str(); }
+
+int OHXDeviceCount(int* out) {
+  API_BEGIN();
+  if (out == nullptr) throw OhxError("OHXDeviceCount: out is NULL");
+  *out = device_count_or_throw();
+  API_END();
+}
+
+int XGDMatrixCreateFromMat(const float* data, bst_ulong nrow, bst_ulong ncol, float missing, DMatrixHandle* out) {
+  API_BEGIN();
+  if (out == nullptr) throw OhxError("XGDMatrixCreateFromMat: out is NULL");
+  if (data == nullptr && nrow * ncol != 0) throw OhxError("XGDMatrixCreateFromMat: data is NULL");
+  DeviceInfo dev = use_device(-1);
+  auto d = std::make_unique<DMatrixObj>();
+  d->nrow = nrow;
+  d->ncol = ncol;
+  d->missing = missing;
+  d->device = dev.ordinal;
+  const size_t count = (size_t)nrow * (size_t)ncol;
+  d->owned.ensure(count);
+  d->d_data = d->owned.p;
+  if (count) {
+    HIP_CHECK(hipMemcpy(d->owned.p, data, count * sizeof(float), hipMemcpyHostToDevice));
+    // xgboost 1.6.0 (SparsePage::Push): "Input data contains `inf` or `nan`"
+    DevBuf<uint32_t> flag;
+    flag.ensure(1);
+    HIP_CHECK(hipMemset(flag.p, 0, sizeof(uint32_t)));
+    HIP_CHECK(launch_scan_dense(d->owned.p, count, missing, flag.p, nullptr));
+    uint32_t h = 0;
+    HIP_CHECK(hipMemcpy(&h, flag.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (h & kFlagInfInput) throw OhxError("Input data contains `inf` or `nan`");
+  }
+  *out = d.release();
+  API_END();
+}
+
+int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong ncol, float missing, DMatrixHandle* out) {
+  API_BEGIN();
+  if (out == nullptr) throw OhxError("OHXDMatrixCreateFromDevice: out is NULL");
+  if (d_data == nullptr && nrow * ncol != 0) throw OhxError("OHXDMatrixCreateFromDevice: d_data is NULL");
+  DeviceInfo dev = use_device(-1);
+  auto d = std::make_unique<DMatrixObj>();
+  d->nrow = nrow;
+  d->ncol = ncol;
+  d->missing = missing;
+  d->d_data = d_data;
+  d->device = dev.ordinal;
+  *out = d.release();
+  API_END();
+}
+
+int XGDMatrixFree(DMatrixHandle handle) {
+  API_BEGIN();
+  DMatrixObj* d = as_dmat(handle);
+  d->magic = 0;
+  delete d;
+  API_END();
+}
+
+int XGDMatrixNumRow(DMatrixHandle handle, bst_ulong* out) {
+  API_BEGIN();
+  if (out == nullptr) throw OhxError("XGDMatrixNumRow: out is NULL");
+  *out = as_dmat(handle)->nrow;
+  API_END();
+}
+
+int XGDMatrixNumCol(DMatrixHandle handle, bst_ulong* out) {
+  API_BEGIN();
+  if (out == nullptr) throw OhxError("XGDMatrixNumCol: out is NULL");
+  *out = as_dmat(handle)->ncol;
+  API_END();
+}
+
+int XGDMatrixSaveBinary(DMatrixHandle handle, const char* fname, int silent) {
+  API_BEGIN();
+  (void)silent;
+  DMatrixObj* d = as_dmat(handle);
+  if (fname == nullptr) throw OhxError("XGDMatrixSaveBinary: fname is NULL");
+  const size_t count = (size_t)d->nrow * (size_t)d->ncol;
+  std::vector<float> host(count);
+  if (count) {
+    HIP_CHECK(hipSetDevice(d->device));
+    HIP_CHECK(hipMemcpy(host.data(), d->d_data, count * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  std::ofstream o(fname, std::ios::binary);
+  if (!o) throw OhxError(std::string("cannot open '") + fname + "' for writing");
+  o.write("OHXDMAT1", 8);
+  o.write((const char*)&d->nrow, 8);
+  o.write((const char*)&d->ncol, 8);
+  o.write((const char*)&d->missing, 4);
+  o.write((const char*)host.data(), (std::streamsize)(count * sizeof(float)));
+  if (!o) throw OhxError(std::string("failed writing '") + fname + "'");
+  API_END();
+}
+
+int XGDMatrixCreateFromFile(const char* fname, int silent, DMatrixHandle* out) {
+  API_BEGIN();
+  (void)silent;
+  if (fname == nullptr || out == nullptr) throw OhxError("XGDMatrixCreateFromFile: NULL argument");
+  std::string uri(fname), path(fname);
+  bool csv = false;
+  size_t q = uri.find('?');
+  if (q != std::string::npos) {
+    path = uri.substr(0, q);
+    csv = uri.find("format=csv", q) != std::string::npos;
+  }
+  if (ends_with(path, ".csv")) csv = true;
+  std::ifstream in(path, std::ios::binary);
+  if (!in) throw OhxError("cannot open '" + path + "'");
+  std::vector<float> host;
+  uint64_t nrow = 0, ncol = 0;
+  float missing = NAN;
+  if (csv) {
+    std::string line;
+    while (std::getline(in, line)) {
+      if (line.empty()) continue;
+      uint64_t c = 0;
+      std::stringstream ss(line);
+      std::string cell;
+      while (std::getline(ss, cell, ',')) {
+        host.push_back(cell.empty() ? NAN : strtof(cell.c_str(), nullptr));
+        ++c;
+      }
+      if (ncol == 0) ncol = c;
+      if (c != ncol) throw OhxError("CSV '" + path + "': ragged row " + std::to_string(nrow));
+      ++nrow;
+    }
+  } else {
+    char magic[8];
+    in.read(magic, 8);
+    if (!in || memcmp(magic, "OHXDMAT1", 8) != 0)
+      throw OhxError("'" + path + "' is not a dense matrix saved by XGDMatrixSaveBinary of this library "
+                     "(xgboost's own binary DMatrix cache and libsvm text are not supported)");
+    in.read((char*)&nrow, 8);
+    in.read((char*)&ncol, 8);
+    in.read((char*)&missing, 4);
+    host.resize((size_t)nrow * (size_t)ncol);
+    in.read((char*)host.data(), (std::streamsize)(host.size() * sizeof(float)));
+    if (!in) throw OhxError("'" + path + "' is truncated");
+  }
+  int rc = XGDMatrixCreateFromMat(host.data(), nrow, ncol, missing, out);
+  if (rc != 0) throw OhxError(g_last_error);
+  API_END();
+}
+
+int XGBoosterCreate(const DMatrixHandle dmats[], bst_ulong len, BoosterHandle* out) {
+  API_BEGIN();
+  if (out == nullptr) throw OhxError("XGBoosterCreate: out is NULL");
+  // The reference passes one handle BY VALUE with len == 0 (OH_GridCompMod.F90:255-256):
+  // with len == 0 the pointer is not an array and must not be read.
+  for (bst_ulong i = 0; i < len; ++i) (void)as_dmat(dmats[i]);
+  *out = new BoosterObj();
+  API_END();
+}
+
+int XGBoosterFree(BoosterHandle handle) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (b->uploaded) (void)hipSetDevice(b->dev.ordinal);
+  b->magic = 0;
+  delete b;
+  API_END();
+}
+
+int XGBoosterLoadModel(BoosterHandle handle, const char* fname) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (fname == nullptr) throw OhxError("XGBoosterLoadModel: fname is NULL");
+  Forest f = load_model_file(fname);
+  f.validate();
+  invalidate_device_state(*b);
+  b->forest = std::move(f);
+  b->loaded = true;
+  API_END();
+}
+
+int XGBoosterLoadModelFromBuffer(BoosterHandle handle, const void* buf, bst_ulong len) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  Forest f = load_model_buffer(buf, (size_t)len);
+  f.validate();
+  invalidate_device_state(*b);
+  b->forest = std::move(f);
+  b->loaded = true;
+  API_END();
+}
+
+int XGBoosterSaveModel(BoosterHandle handle, const char* fname) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (fname == nullptr) throw OhxError("XGBoosterSaveModel: fname is NULL");
+  if (!b->loaded) throw OhxError("XGBoosterSaveModel: the booster holds no model");
+  save_model_file(b->forest, fname);
+  API_END();
+}
+
+int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (name == nullptr || value == nullptr) throw OhxError("XGBoosterSetParam: NULL argument");
+  const std::string n(name), v(value);
+  if (n == "ohx_kernel") {
+    if (v != "auto" && v != "wide" && v != "packed1" && v != "packed2" && v != "packed4")
+      throw OhxError("ohx_kernel must be one of auto, wide, packed1, packed2, packed4");
+    b->kernel_name = v;
+  } else if (n == "ohx_top_levels") {
+    int k = atoi(value);
+    if (k < 1 || k > 30) throw OhxError("ohx_top_levels must be in 1..30");
+    if (k != b->layout.top_levels) invalidate_device_state(*b);
+    b->layout.top_levels = k;
+  } else if (n == "ohx_line_slots") {
+    int k = atoi(value);
+    if (k < 0 || k > 1024 || (k & 1)) throw OhxError("ohx_line_slots must be even, 0..1024");
+    if (k != b->layout.line_slots) invalidate_device_state(*b);
+    b->layout.line_slots = k;
+  } else if (n == "ohx_min_chunk") {
+    int k = atoi(value);
+    if (k < 2 || k > 1024) throw OhxError("ohx_min_chunk must be in 2..1024");
+    if (k != b->layout.min_chunk) invalidate_device_state(*b);
+    b->layout.min_chunk = k;
+  } else if (n == "ohx_device") {
+    int k = atoi(value);
+    if (k != b->device_pref) invalidate_device_state(*b);
+    b->device_pref = k;
+  }
+  // any other name is an xgboost training/runtime parameter with no meaning here
+  API_END();
+}
+
+int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, unsigned ntree_limit, int training,
+                     bst_ulong* out_len, const float** out_result) {
+  API_BEGIN();
+  (void)training;
+  BoosterObj* b = as_booster(handle);
+  DMatrixObj* d = as_dmat(dmat);
+  if (out_len == nullptr || out_result == nullptr) throw OhxError("XGBoosterPredict: NULL output argument");
+  if (!b->loaded) throw OhxError("the booster holds no model: call XGBoosterLoadModel first");
+  uint32_t t0, t1;
+  tree_range(*b, ntree_limit, &t0, &t1);
+  const size_t per_row = (option_mask == 16) ? (size_t)(t1 - t0) : 1;
+  const size_t count = (size_t)d->nrow * per_row;
+  ensure_uploaded(*b);
+  b->d_pred.ensure(count);
+  b->h_pred.ensure(count);
+  launch_predict_checked(*b, *d, option_mask, ntree_limit, b->d_pred.p, nullptr);
+  if (count) HIP_CHECK(hipMemcpy(b->h_pred.p, b->d_pred.p, count * sizeof(float), hipMemcpyDeviceToHost));
+  raise_flag_errors(*b, nullptr);
+  *out_len = count;
+  *out_result = b->h_pred.p;
+  API_END();
+}
+
+int OHXBoosterPredictDevice(BoosterHandle handle, DMatrixHandle dmat, int option_mask, unsigned ntree_limit,
+                            float* d_out, void* stream) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  DMatrixObj* d = as_dmat(dmat);
+  if (d_out == nullptr && d->nrow != 0) throw OhxError("OHXBoosterPredictDevice: d_out is NULL");
+  launch_predict_checked(*b, *d, option_mask, ntree_limit, d_out, static_cast<hipStream_t>(stream));
+  API_END();
+}
+
+int OHXBoosterCheck(BoosterHandle handle, void* stream) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  ensure_uploaded(*b);
+  raise_flag_errors(*b, static_cast<hipStream_t>(stream));
+  API_END();
+}
+
+static void fields_common(BoosterObj& b, FieldsArgs& a, const int32_t is2d[], int nfield, int pl_feature, int im,
+                          int jm, int km, int k1, int k2, float missing, int apply_pow10, float ohscale) {
+  if (nfield < 0 || nfield > 32) throw OhxError("predict_fields: nfield must be 0..32");
+  if ((uint32_t)nfield > b.forest.num_feature)
+    throw OhxError("Number of columns does not match number of features in booster (" + std::to_string(nfield) +
+                   " vs. " + std::to_string(b.forest.num_feature) + ")");
+  if (b.forest.num_feature > 32) throw OhxError("predict_fields supports boosters with at most 32 features");
+  if (im <= 0 || jm <= 0 || km <= 0) throw OhxError("predict_fields: im, jm, km must be positive");
+  if (k1 < 1 || k2 > km || k2 < k1 - 1) throw OhxError("predict_fields: need 1 <= k1, k2 <= km, k2 >= k1 - 1");
+  if (!objective_is_identity(b.forest.objective))
+    throw OhxError("objective '" + b.forest.objective + "' is not supported by predict_fields");
+  a.is2d_mask = 0;
+  for (int f = 0; f < nfield; ++f)
+    if (is2d[f]) a.is2d_mask |= (1u << f);
+  a.pl_feature = pl_feature < 0 ? 0xFFFFFFFFu : (uint32_t)pl_feature;
+  a.nfield = (uint32_t)nfield;
+  a.im = im;
+  a.jm = jm;
+  a.km = km;
+  a.k1 = k1 - 1;
+  a.k2 = k2 - 1;
+  a.missing = missing;
+  tree_range(b, 0, &a.tree_begin, &a.tree_end);
+  a.apply_pow10 = apply_pow10;
+  a.scale = ohscale;
+  a.flags = b.d_flags.p;
+}
+
+int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fields[], const int32_t is2d[],
+                                  int nfield, int pl_feature, int im, int jm, int km, int k1, int k2, float missing,
+                                  int apply_pow10, float ohscale, float* d_oh_ml, float* d_margin, void* stream) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (d_fields == nullptr || is2d == nullptr || d_oh_ml == nullptr) throw OhxError("predict_fields: NULL argument");
+  ensure_uploaded(*b);
+  FieldsArgs a{};
+  fields_common(*b, a, is2d, nfield, pl_feature, im, jm, km, k1, k2, missing, apply_pow10, ohscale);
+  for (int f = 0; f < nfield; ++f) {
+    if (d_fields[f] == nullptr) throw OhxError("predict_fields: field " + std::to_string(f) + " is NULL");
+    a.field[f] = d_fields[f];
+  }
+  a.out = d_oh_ml;
+  a.margin_out = d_margin;
+  if (pick_kernel(*b) == KernelKind::Wide) ensure_wide(*b);
+  if (a.k2 >= a.k1)
+    HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus,
+                                    static_cast<hipStream_t>(stream)));
+  API_END();
+}
+
+int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], const int32_t is2d[], int nfield,
+                            int pl_feature, int im, int jm, int km, int k1, int k2, float missing, int apply_pow10,
+                            float ohscale, float* oh_ml, float* margin) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (fields == nullptr || is2d == nullptr || oh_ml == nullptr) throw OhxError("predict_fields: NULL argument");
+  ensure_uploaded(*b);
+  FieldsArgs a{};
+  fields_common(*b, a, is2d, nfield, pl_feature, im, jm, km, k1, k2, missing, apply_pow10, ohscale);
+  if (a.k2 < a.k1) return 0;
+  const size_t plane = (size_t)im * (size_t)jm;
+  const size_t nlev = (size_t)(a.k2 - a.k1 + 1);
+  const size_t nrow = plane * nlev;
+  if (b->d_stage.size() < (size_t)nfield) b->d_stage.resize((size_t)nfield);
+  // only the slab k1..k2 of each 3-D field crosses PCIe
+  for (int f = 0; f < nfield; ++f) {
+    if (fields[f] == nullptr) throw OhxError("predict_fields: field " + std::to_string(f) + " is NULL");
+    const bool two_d = is2d[f] != 0;
+    const size_t count = two_d ? plane : nrow;
+    const float* src = two_d ? fields[f] : fields[f] + plane * (size_t)a.k1;
+    b->d_stage[(size_t)f].ensure(count);
+    HIP_CHECK(hipMemcpyAsync(b->d_stage[(size_t)f].p, src, count * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    a.field[f] = b->d_stage[(size_t)f].p;
+  }
+  a.src_k0 = a.k1;
+  a.out_k0 = a.k1;
+  b->d_stage_out.ensure(nrow);
+  a.out = b->d_stage_out.p;
+  if (margin) {
+    b->d_stage_margin.ensure(nrow);
+    a.margin_out = b->d_stage_margin.p;
+  }
+  if (pick_kernel(*b) == KernelKind::Wide) ensure_wide(*b);
+  HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus, nullptr));
+  HIP_CHECK(hipMemcpy(oh_ml + plane * (size_t)a.k1, b->d_stage_out.p, nrow * sizeof(float), hipMemcpyDeviceToHost));
+  if (margin) HIP_CHECK(hipMemcpy(margin, b->d_stage_margin.p, nrow * sizeof(float), hipMemcpyDeviceToHost));
+  raise_flag_errors(*b, nullptr);
+  API_END();
+}
+
+int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (info == nullptr) throw OhxError("OHXBoosterGetInfo: info is NULL");
+  if (!b->loaded) throw OhxError("the booster holds no model");
+  // host-only: placement can be computed without a device
+  Placement local;
+  const Placement* p = &b->placement;
+  bool packed_ok = b->packed_ok;
+  if (!b->uploaded) {
+    local = place_forest(b->forest, b->layout);
+    p = &local;
+    packed_ok = packed_format_fits(b->forest, local);
+  }
+  const bool packed_used = packed_ok && b->kernel_name != "wide";
+  info[0] = b->forest.trees.size();
+  info[1] = p->real_nodes;
+  info[2] = p->num_slots;
+  info[3] = p->num_slots * (packed_used ? sizeof(PackedNode) : sizeof(WideNode));
+  info[4] = (bst_ulong)p->max_depth;
+  info[5] = b->forest.num_feature;
+  info[6] = packed_used ? 1 : 0;
+  info[7] = 0;
+  API_END();
+}
+
+int OHXSynthRowsDevice(uint32_t seed, int im, int jm, int km, bst_ulong row_begin, bst_ulong nrows, float* d_out,
+                       void* stream) {
+  API_BEGIN();
+  (void)device_count_or_throw();
+  if (d_out == nullptr && nrows) throw OhxError("OHXSynthRowsDevice: d_out is NULL");
+  if (im <= 0 || jm <= 0 || km <= 0) throw OhxError("OHXSynthRowsDevice: bad grid");
+  if (row_begin + nrows > (bst_ulong)im * (bst_ulong)jm * (bst_ulong)km)
+    throw OhxError("OHXSynthRowsDevice: row range exceeds the grid");
+  HIP_CHECK(launch_synth_rows(seed, im, jm, km, row_begin, nrows, d_out, static_cast<hipStream_t>(stream)));
+  API_END();
+}
+
+int OHXSynthFieldDevice(uint32_t seed, int feature, int im, int jm, int km, float* d_out, void* stream) {
+  API_BEGIN();
+  (void)device_count_or_throw();
+  if (d_out == nullptr) throw OhxError("OHXSynthFieldDevice: d_out is NULL");
+  if (im <= 0 || jm <= 0 || km <= 0 || feature < -1 || feature >= 27) throw OhxError("OHXSynthFieldDevice: bad argument");
+  HIP_CHECK(launch_synth_field(seed, feature, im, jm, km, d_out, static_cast<hipStream_t>(stream)));
+  API_END();
+}
+
+int OHXInjectMissingDevice(float* d_rows, bst_ulong count, uint32_t seed, uint32_t rate_per_million, float missing,
+                           void* stream) {
+  API_BEGIN();
+  (void)device_count_or_throw();
+  if (d_rows == nullptr && count) throw OhxError("OHXInjectMissingDevice: d_rows is NULL");
+  HIP_CHECK(launch_inject_missing(d_rows, count, seed, rate_per_million, missing, static_cast<hipStream_t>(stream)));
+  API_END();
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,153 @@
+#include "flatten.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <deque>
+
+namespace ohx {
+
+namespace {
+
+struct Pair {
+  int32_t l, r;
+  int depth;
+};
+
+}  // namespace
+
+Placement place_forest(const Forest& f, const LayoutParams& lp) {
+  Placement p;
+  p.layout = lp;
+  const int line = lp.line_slots;
+  if (line != 0 && (line < 2 || (line & 1))) throw OhxError("layout: line_slots must be even and >= 2");
+  const int top = std::max(1, lp.top_levels);
+  p.roots.resize(f.trees.size());
+  p.slot_of.resize(f.trees.size());
+  uint64_t next = 0;
+  auto align_line = [&]() {
+    if (line > 0) next = (next + (uint64_t)line - 1) / (uint64_t)line * (uint64_t)line;
+  };
+  for (size_t ti = 0; ti < f.trees.size(); ++ti) {
+    const Tree& t = f.trees[ti];
+    std::vector<uint32_t>& slot = p.slot_of[ti];
+    slot.assign(t.size(), kNoSlot);
+    align_line();
+    // ---- breadth-first top ----
+    p.roots[ti] = (uint32_t)next;
+    slot[0] = (uint32_t)next++;
+    p.real_nodes += 1;
+    std::vector<int32_t> frontier{0}, nextf;
+    int depth = 0;
+    std::vector<Pair> pending;
+    const bool bfs_all = (line == 0);
+    while (!frontier.empty()) {
+      nextf.clear();
+      const bool last_top_level = (!bfs_all && depth == top - 1);
+      for (int32_t n : frontier) {
+        if (t.left[(size_t)n] == -1) continue;
+        const int32_t l = t.left[(size_t)n], r = t.right[(size_t)n];
+        if (last_top_level) {
+          pending.push_back({l, r, depth + 1});
+        } else {
+          slot[(size_t)l] = (uint32_t)next++;
+          slot[(size_t)r] = (uint32_t)next++;
+          p.real_nodes += 2;
+          nextf.push_back(l);
+          nextf.push_back(r);
+        }
+      }
+      if (!nextf.empty()) p.max_depth = std::max(p.max_depth, depth + 1);
+      if (last_top_level) break;
+      frontier.swap(nextf);
+      ++depth;
+    }
+    if (pending.empty()) continue;
+    // ---- line-packed deep part: depth-first over subtrees, breadth-first inside a line ----
+    align_line();
+    std::vector<Pair> stack(pending.rbegin(), pending.rend());
+    std::deque<Pair> q;
+    while (!stack.empty()) {
+      Pair start = stack.back();
+      stack.pop_back();
+      const uint64_t free_in_line = (uint64_t)line - next % (uint64_t)line;
+      if (free_in_line < (uint64_t)lp.min_chunk && free_in_line != (uint64_t)line) align_line();
+      q.clear();
+      q.push_back(start);
+      bool placed_any = false;
+      while (!q.empty()) {
+        if (placed_any && next % (uint64_t)line == 0) break;  // the line is full
+        Pair pr = q.front();
+        q.pop_front();
+        slot[(size_t)pr.l] = (uint32_t)next++;
+        slot[(size_t)pr.r] = (uint32_t)next++;
+        p.real_nodes += 2;
+        placed_any = true;
+        p.max_depth = std::max(p.max_depth, pr.depth);
+        for (int32_t c : {pr.l, pr.r})
+          if (t.left[(size_t)c] != -1) q.push_back({t.left[(size_t)c], t.right[(size_t)c], pr.depth + 1});
+      }
+      // whatever did not fit starts new chunks, nearest relatives first
+      for (auto it = q.rbegin(); it != q.rend(); ++it) stack.push_back(*it);
+    }
+  }
+  align_line();
+  p.num_slots = next;
+  if (p.num_slots >= 0xFFFFFFF0ull) throw OhxError("booster too large: more than 2**32 node slots");
+  return p;
+}
+
+bool packed_format_fits(const Forest& f, const Placement& p) {
+  return f.num_feature <= (1u << kPackedFeatureBits) && p.num_slots < kPackedMaxSlots;
+}
+
+std::vector<PackedNode> emit_packed(const Forest& f, const Placement& p, std::vector<int32_t>* orig_id) {
+  if (!packed_format_fits(f, p)) throw OhxError("booster does not fit the packed node format");
+  std::vector<PackedNode> out((size_t)p.num_slots, PackedNode{0u, 0u});
+  if (orig_id) orig_id->assign((size_t)p.num_slots, -1);
+  for (size_t ti = 0; ti < f.trees.size(); ++ti) {
+    const Tree& t = f.trees[ti];
+    const auto& slot = p.slot_of[ti];
+    for (size_t i = 0; i < t.size(); ++i) {
+      if (slot[i] == kNoSlot) continue;
+      PackedNode nd;
+      memcpy(&nd.value_bits, &t.value[i], 4);
+      if (t.left[i] == -1) {
+        nd.meta = 0u;
+      } else {
+        const uint32_t ls = slot[(size_t)t.left[i]], rs = slot[(size_t)t.right[i]];
+        if (rs != ls + 1) throw OhxError("internal error: placement broke sibling adjacency");
+        nd.meta = (rs << 6) | ((uint32_t)(t.default_left[i] ? 1u : 0u) << 5) | (t.feature[i] & 31u);
+      }
+      out[slot[i]] = nd;
+      if (orig_id) (*orig_id)[slot[i]] = (int32_t)i;
+    }
+  }
+  return out;
+}
+
+std::vector<WideNode> emit_wide(const Forest& f, const Placement& p) {
+  std::vector<WideNode> out((size_t)p.num_slots, WideNode{0.0f, 0u, 0u, -1});
+  for (size_t ti = 0; ti < f.trees.size(); ++ti) {
+    const Tree& t = f.trees[ti];
+    const auto& slot = p.slot_of[ti];
+    for (size_t i = 0; i < t.size(); ++i) {
+      if (slot[i] == kNoSlot) continue;
+      WideNode nd;
+      nd.value = t.value[i];
+      nd.orig_id = (int32_t)i;
+      if (t.left[i] == -1) {
+        nd.left = 0u;
+        nd.feat_dl = 0u;
+      } else {
+        const uint32_t ls = slot[(size_t)t.left[i]], rs = slot[(size_t)t.right[i]];
+        if (rs != ls + 1) throw OhxError("internal error: placement broke sibling adjacency");
+        nd.left = ls;
+        nd.feat_dl = t.feature[i] | ((uint32_t)(t.default_left[i] ? 1u : 0u) << 31);
+      }
+      out[slot[i]] = nd;
+    }
+  }
+  return out;
+}
+
+}  // namespace ohx

@@ -1,0 +1,68 @@
+// Flattening of a Forest into the node arrays the HIP traversal kernels read.
+//
+// Two device formats, both with absolute child slots into one array for the whole
+// booster and "right child = left child + 1" by construction:
+//
+//  * packed (8 B/node; boosters with <= 32 features and < 2**26 slots):
+//      .value_bits = float bits of the split condition (or the leaf value)
+//      .meta       = (right_child_slot << 6) | (default_left << 5) | feature
+//                    0 => leaf
+//    Storing the RIGHT child lets the step be one subtract-with-borrow:
+//      next = right - (x < cond).
+//  * wide (16 B/node, any feature count): {value, left_child_slot (0 => leaf),
+//    feature | default_left << 31, original node id}.
+//
+// Slot 0 is the root of tree 0 and therefore never a child, which is what makes
+// "0 => leaf" unambiguous.
+//
+// Placement ("layout") is what makes the deep levels affordable on MI355X: the
+// top `top_levels` levels of every tree are stored breadth-first (a few KB per
+// tree that stay in L1/L2), and below that sibling pairs are packed greedily,
+// breadth first, into 128-byte lines (16 packed slots), so that a walk touches
+// about one new cache line per three levels instead of one per level.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "forest.hpp"
+
+namespace ohx {
+
+struct LayoutParams {
+  int top_levels = 9;    // levels stored breadth-first per tree (root = level 0)
+  int line_slots = 16;   // slots per packed line below the top; 0 => breadth-first all the way
+  int min_chunk = 6;     // do not start a new subtree in a line with fewer free slots than this
+};
+
+struct PackedNode {  // 8 bytes
+  uint32_t value_bits;
+  uint32_t meta;
+};
+
+struct WideNode {  // 16 bytes
+  float value;
+  uint32_t left;     // absolute slot of the left child, 0 => leaf
+  uint32_t feat_dl;  // feature | default_left << 31
+  int32_t orig_id;   // node id inside its tree in the model file (for pred_leaf)
+};
+
+// Where every node of every tree lives in the flattened array.
+struct Placement {
+  LayoutParams layout;
+  uint64_t num_slots = 0;
+  uint64_t real_nodes = 0;                       // nodes reachable from the roots
+  int max_depth = 0;
+  std::vector<uint32_t> roots;                   // slot of each tree's root
+  std::vector<std::vector<uint32_t>> slot_of;    // [tree][node] -> slot, 0xFFFFFFFF if unreachable
+};
+
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+constexpr int kPackedFeatureBits = 5;
+constexpr uint64_t kPackedMaxSlots = 1ull << 26;
+
+Placement place_forest(const Forest& f, const LayoutParams& lp);
+bool packed_format_fits(const Forest& f, const Placement& p);
+std::vector<PackedNode> emit_packed(const Forest& f, const Placement& p, std::vector<int32_t>* orig_id);
+std::vector<WideNode> emit_wide(const Forest& f, const Placement& p);
+
+}  // namespace ohx

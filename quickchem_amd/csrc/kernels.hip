@@ -1,0 +1,461 @@
+// gfx950 (MI355X, CDNA4) kernels of the OH predictor.
+//
+// What they replace: libxgboost's CPU predictor behind XGBoosterPredict, called
+// once per OH alarm tick from predict_OH_with_XGB
+// (/root/reference OH_GridComp/OH_GridCompMod.F90:356), plus the passes around
+// it: the SoA->AoS gather (:308-345), the DMatrix copy (:347) and the
+// 10**pred scatter (:364-374).
+//
+// Prediction semantics (xgboost 1.6.0 cpu_predictor / predict_fn):
+//   pred = base_score; for t in order: pred += leaf_t(row)      (float32, sequential)
+//   walk: missing (NaN, or == `missing`) -> default child; else x < cond -> left, else right
+//
+// Execution shape: memory/latency bound pointer chasing, no MFMA.  One lane owns
+// one gridcell; the wave's 64 feature vectors sit in LDS feature-major
+// ([feature][lane], bank = lane % 32, conflict-free for any per-lane feature
+// index); CHAINS trees are walked at once per lane so that several dependent
+// node loads are in flight per lane, and their leaves are added in tree order.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+#include "synth_common.h"
+
+namespace ohx {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;                  // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ bool is_inf(float v) { return __builtin_isinf(v); }
+
+// ------------------------------------------------------------------ tile fill
+
+// Row-major rows -> LDS tile[f * 64 + lane].  `missing` values become NaN so the
+// walk has one notion of missing.  Returns true if this lane's row has any NaN.
+__device__ __forceinline__ bool fill_tile_rows(float* __restrict__ tile, const float* __restrict__ rows,
+                                               uint64_t row, bool valid, uint32_t ncol, uint32_t nfeat,
+                                               float missing, bool missing_is_nan, uint32_t* flags) {
+  bool any_nan = false;
+  bool any_inf = false;
+  const float qnan = __builtin_nanf("");
+  const float* p = rows + row * (uint64_t)ncol;
+  uint32_t f = 0;
+  if (valid) {
+    for (; f + 4 <= ncol; f += 4) {
+      f4u v = __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p + f));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float x = v[c];
+        any_inf |= is_inf(x);
+        if (!missing_is_nan && x == missing) x = qnan;
+        any_nan |= (x != x);
+        tile[(f + c) * kWave] = x;
+      }
+    }
+    for (; f < ncol; ++f) {
+      float x = __builtin_nontemporal_load(p + f);
+      any_inf |= is_inf(x);
+      if (!missing_is_nan && x == missing) x = qnan;
+      any_nan |= (x != x);
+      tile[f * kWave] = x;
+    }
+    // a booster with more features than the matrix has columns sees them as missing
+    for (; f < nfeat; ++f) {
+      tile[f * kWave] = qnan;
+      any_nan = true;
+    }
+    if (any_inf && !is_inf(missing) && flags) atomicOr(flags, kFlagInfInput);
+  } else {
+    for (; f < nfeat; ++f) tile[f * kWave] = 0.0f;
+  }
+  return any_nan;
+}
+
+// ------------------------------------------------------------------ walks
+
+template <bool HAS_MISSING>
+__device__ __forceinline__ uint32_t step_packed(uint2 nd, const float* __restrict__ tile) {
+  const float x = tile[(nd.y & 31u) * kWave];
+  const float cond = __uint_as_float(nd.x);
+  bool go_left = x < cond;
+  if (HAS_MISSING) go_left = go_left || ((x != x) && (nd.y & 32u));
+  return (nd.y >> 6) - (go_left ? 1u : 0u);
+}
+
+template <int CHAINS, bool HAS_MISSING>
+__device__ __forceinline__ float walk_packed(const uint2* __restrict__ nodes, const uint32_t* __restrict__ roots,
+                                             uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile) {
+  for (uint32_t t = t0; t < t1; t += CHAINS) {
+    uint2 nd[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) {
+      const uint32_t tt = (t + c < t1) ? t + c : t1 - 1;  // clamp: the duplicate walk is discarded
+      nd[c] = nodes[roots[tt]];
+    }
+    bool more;
+    do {
+      more = false;
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) {
+        if (nd[c].y != 0u) {
+          const uint32_t n = step_packed<HAS_MISSING>(nd[c], tile);
+          nd[c] = nodes[n];
+          more = true;
+        }
+      }
+    } while (more);
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+      if (t + c < t1) acc += __uint_as_float(nd[c].x);
+  }
+  return acc;
+}
+
+template <bool HAS_MISSING>
+__device__ __forceinline__ float walk_wide_tile(const uint4* __restrict__ nodes, const uint32_t* __restrict__ roots,
+                                                uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile) {
+  for (uint32_t t = t0; t < t1; ++t) {
+    uint4 nd = nodes[roots[t]];
+    while (nd.y != 0u) {
+      const float x = tile[(nd.z & 0x7FFFFFFFu) * kWave];
+      bool go_left = x < __uint_as_float(nd.x);
+      if (HAS_MISSING) go_left = go_left || ((x != x) && (nd.z >> 31));
+      nd = nodes[nd.y + (go_left ? 0u : 1u)];
+    }
+    acc += __uint_as_float(nd.x);
+  }
+  return acc;
+}
+
+template <int CHAINS>
+__device__ __forceinline__ float walk_tile(const DeviceForest& fr, uint32_t t0, uint32_t t1, const float* tile,
+                                           bool wave_has_missing) {
+  float acc = fr.base_score;
+  if constexpr (CHAINS > 0) {
+    const uint2* nodes = reinterpret_cast<const uint2*>(fr.packed);
+    constexpr int C = CHAINS;
+    return wave_has_missing ? walk_packed<C, true>(nodes, fr.roots, t0, t1, acc, tile)
+                            : walk_packed<C, false>(nodes, fr.roots, t0, t1, acc, tile);
+  } else {
+    const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
+    return wave_has_missing ? walk_wide_tile<true>(nodes, fr.roots, t0, t1, acc, tile)
+                            : walk_wide_tile<false>(nodes, fr.roots, t0, t1, acc, tile);
+  }
+}
+
+// ------------------------------------------------------------------ kernels
+
+// AoS rows in, margins out.  CHAINS = 0 selects the 16-byte node format.
+template <int CHAINS>
+__global__ __launch_bounds__(kBlock) void predict_rows_tile_kernel(DeviceForest fr, PredictArgs a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  float* tile = lds + (size_t)wave * fr.num_feature * kWave + lane;
+  const bool missing_is_nan = a.missing != a.missing;
+  const uint64_t ntiles = (a.nrow + kWave - 1) / kWave;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  for (uint64_t tile_id = wave_id; tile_id < ntiles; tile_id += nwaves) {
+    const uint64_t row = tile_id * kWave + lane;
+    const bool valid = row < a.nrow;
+    const bool lane_nan = fill_tile_rows(tile, a.rows, row, valid, a.ncol, fr.num_feature, a.missing,
+                                         missing_is_nan, a.flags);
+    const bool wave_nan = __any(lane_nan);
+    // the tile is private to this wave: its own LDS writes are ordered before its reads
+    const float acc = walk_tile<CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
+    if (valid) __builtin_nontemporal_store(acc, a.out + row);
+  }
+}
+
+// Any feature count, no LDS: every lane reads its own row from global memory.
+template <bool PRED_LEAF>
+__global__ __launch_bounds__(kBlock) void predict_rows_direct_kernel(DeviceForest fr, PredictArgs a) {
+  const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
+  const bool missing_is_nan = a.missing != a.missing;
+  const bool missing_is_inf = is_inf(a.missing);
+  const uint32_t ntree = a.tree_end - a.tree_begin;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; row < a.nrow; row += stride) {
+    const float* x = a.rows + row * (uint64_t)a.ncol;
+    float acc = fr.base_score;
+    bool any_inf = false;
+    for (uint32_t t = a.tree_begin; t < a.tree_end; ++t) {
+      uint4 nd = nodes[fr.roots[t]];
+      while (nd.y != 0u) {
+        const uint32_t f = nd.z & 0x7FFFFFFFu;
+        bool miss = true;
+        bool lt = false;
+        if (f < a.ncol) {
+          const float v = x[f];
+          any_inf |= is_inf(v);
+          miss = (v != v) || (!missing_is_nan && v == a.missing);
+          lt = v < __uint_as_float(nd.x);
+        }
+        const bool go_left = miss ? (nd.z >> 31) != 0u : lt;
+        nd = nodes[nd.y + (go_left ? 0u : 1u)];
+      }
+      if (PRED_LEAF) a.out[row * (uint64_t)ntree + (t - a.tree_begin)] = (float)(int32_t)nd.w;
+      else acc += __uint_as_float(nd.x);
+    }
+    if (!PRED_LEAF) a.out[row] = acc;
+    if (any_inf && !missing_is_inf && a.flags) atomicOr(a.flags, kFlagInfInput);
+  }
+}
+
+// The fused path: reads the MAPL fields in place (lane = consecutive i, coalesced),
+// applies PL/100 (OH_GridCompMod.F90:314), walks, writes 10**pred * OHscale
+// (OH_GridCompMod.F90:369,1569) into OH_ML(i,j,k1..k2).
+template <int CHAINS>
+__global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr, FieldsArgs a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  float* tile = lds + (size_t)wave * fr.num_feature * kWave + lane;
+  const bool missing_is_nan = a.missing != a.missing;
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t nrow = plane * (uint64_t)(a.k2 - a.k1 + 1);
+  const uint64_t slab = plane * (uint64_t)(a.k1 - a.src_k0);
+  const uint64_t slab_out = plane * (uint64_t)(a.k1 - a.out_k0);
+  const uint64_t ntiles = (nrow + kWave - 1) / kWave;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  const float qnan = __builtin_nanf("");
+  for (uint64_t tile_id = wave_id; tile_id < ntiles; tile_id += nwaves) {
+    const uint64_t m = tile_id * kWave + lane;
+    const bool valid = m < nrow;
+    const uint64_t col = valid ? m % plane : 0;
+    bool lane_nan = false, any_inf = false;
+    for (uint32_t f = 0; f < fr.num_feature; ++f) {
+      float x = qnan;
+      if (valid && f < a.nfield) {
+        const float* src = a.field[f];
+        x = ((a.is2d_mask >> f) & 1u) ? src[col] : __builtin_nontemporal_load(src + slab + m);
+        if (f == a.pl_feature) x = x / 100.0f;
+        any_inf |= is_inf(x);
+        if (!missing_is_nan && x == a.missing) x = qnan;
+      }
+      if (!valid) x = 0.0f;
+      lane_nan |= (x != x);
+      tile[f * kWave] = x;
+    }
+    if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
+    const bool wave_nan = __any(lane_nan);
+    const float acc = walk_tile<CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
+    if (valid) {
+      if (a.margin_out) a.margin_out[m] = acc;
+      float oh = acc;
+      // 10.0**x rounded once from double: agrees with a correctly rounded powf
+      if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);
+      oh = oh * a.scale;
+      a.out[slab_out + m] = oh;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void scan_dense_kernel(const float* __restrict__ data, uint64_t count,
+                                                            float missing, uint32_t* flags) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  bool any_inf = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    any_inf |= is_inf(data[i]);
+  if (any_inf && !is_inf(missing)) atomicOr(flags, kFlagInfInput);
+}
+
+// ------------------------------------------------------------------ synthetic inputs
+
+__global__ __launch_bounds__(kBlock) void synth_rows_kernel(uint32_t seed, int im, int jm, int km, uint64_t row_begin,
+                                                            uint64_t nrows, float* __restrict__ out) {
+  // one thread per (row, feature): consecutive threads write consecutive floats
+  const uint64_t total = nrows * OHX_NFEAT;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t plane = (uint64_t)im * (uint64_t)jm;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const uint64_t r = e / OHX_NFEAT;
+    const int f = (int)(e - r * OHX_NFEAT);
+    const uint64_t m = row_begin + r;
+    const int k = (int)(m / plane);
+    const uint64_t c = m - (uint64_t)k * plane;
+    const int j = (int)(c / (uint64_t)im);
+    const int i = (int)(c - (uint64_t)j * (uint64_t)im);
+    out[e] = ohx_synth_feature(seed, f, i, j, k, im, jm, km);
+  }
+}
+
+// feature >= 0: that feature as a MAPL field ((im,jm) or (im,jm,km); PL in Pa);
+// feature == -1: TROPP (im,jm) in Pa
+__global__ __launch_bounds__(kBlock) void synth_field_kernel(uint32_t seed, int feature, int im, int jm, int km,
+                                                             float* __restrict__ out) {
+  const uint64_t plane = (uint64_t)im * (uint64_t)jm;
+  const bool two_d = feature < 0 || ohx_feature_is_2d(feature);
+  const uint64_t total = two_d ? plane : plane * (uint64_t)km;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += stride) {
+    const int k = (int)(m / plane);
+    const uint64_t c = m - (uint64_t)k * plane;
+    const int j = (int)(c / (uint64_t)im);
+    const int i = (int)(c - (uint64_t)j * (uint64_t)im);
+    float v;
+    if (feature < 0) v = ohx_synth_tropp_pa(seed, i, j);
+    else if (feature == OHX_F_PL) v = ohx_synth_pl_pa(seed, i, j, k, im, jm, km);
+    else v = ohx_synth_feature(seed, feature, i, j, k, im, jm, km);
+    out[m] = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void inject_missing_kernel(float* __restrict__ rows, uint64_t count, uint32_t seed,
+                                                                uint32_t rate_per_million, float missing) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const float qnan = __builtin_nanf("");
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
+    const uint32_t h = ohx_hash4(seed, 0x99000000u, (uint32_t)(e & 0xFFFFFFFFu), (uint32_t)(e >> 32), 0u);
+    if (h % 1000000u < rate_per_million) rows[e] = (h & 0x80000000u) ? missing : qnan;
+  }
+}
+
+int grid_for(uint64_t work_items, int num_cus, int blocks_per_cu) {
+  uint64_t blocks = (work_items + kBlock - 1) / kBlock;
+  uint64_t cap = (uint64_t)num_cus * (uint64_t)blocks_per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <class K>
+int tile_grid(K kernel, size_t lds_bytes, uint64_t nrow, int num_cus) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes) != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  const uint64_t ntiles = (nrow + kWave - 1) / kWave;
+  uint64_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <class K>
+hipError_t ensure_lds(K kernel, size_t lds_bytes) {
+  if (lds_bytes > 64 * 1024)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds_bytes);
+  return hipSuccess;
+}
+
+}  // namespace
+
+const char* kernel_kind_name(KernelKind k) {
+  switch (k) {
+    case KernelKind::Wide: return "wide";
+    case KernelKind::Packed1: return "packed1";
+    case KernelKind::Packed2: return "packed2";
+    case KernelKind::Packed4: return "packed4";
+  }
+  return "?";
+}
+
+hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const PredictArgs& a, int num_cus,
+                          hipStream_t stream) {
+  if (a.nrow == 0) return hipSuccess;
+  const size_t lds = (size_t)kWavesPerBlock * fr.num_feature * kWave * sizeof(float);
+  const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && a.ncol <= fr.num_feature;
+  if (a.pred_leaf || kind == KernelKind::Wide || !tile_ok || fr.packed == nullptr) {
+    if (fr.wide == nullptr) return hipErrorInvalidValue;
+    const int grid = grid_for(a.nrow, num_cus, 8);
+    if (a.pred_leaf) hipLaunchKernelGGL(predict_rows_direct_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, fr, a);
+    else hipLaunchKernelGGL(predict_rows_direct_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, fr, a);
+    return hipGetLastError();
+  }
+  hipError_t e = hipSuccess;
+  switch (kind) {
+    case KernelKind::Packed1: {
+      if ((e = ensure_lds(predict_rows_tile_kernel<1>, lds)) != hipSuccess) return e;
+      const int grid = tile_grid(predict_rows_tile_kernel<1>, lds, a.nrow, num_cus);
+      hipLaunchKernelGGL(predict_rows_tile_kernel<1>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+      break;
+    }
+    case KernelKind::Packed2: {
+      if ((e = ensure_lds(predict_rows_tile_kernel<2>, lds)) != hipSuccess) return e;
+      const int grid = tile_grid(predict_rows_tile_kernel<2>, lds, a.nrow, num_cus);
+      hipLaunchKernelGGL(predict_rows_tile_kernel<2>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+      break;
+    }
+    default: {
+      if ((e = ensure_lds(predict_rows_tile_kernel<4>, lds)) != hipSuccess) return e;
+      const int grid = tile_grid(predict_rows_tile_kernel<4>, lds, a.nrow, num_cus);
+      hipLaunchKernelGGL(predict_rows_tile_kernel<4>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+      break;
+    }
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const FieldsArgs& a, int num_cus,
+                                 hipStream_t stream) {
+  if (a.k2 < a.k1 || a.im <= 0 || a.jm <= 0) return hipSuccess;
+  const uint64_t nrow = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)(a.k2 - a.k1 + 1);
+  const size_t lds = (size_t)kWavesPerBlock * fr.num_feature * kWave * sizeof(float);
+  if (fr.num_feature < 1 || lds > 160 * 1024) return hipErrorInvalidValue;
+  hipError_t e = hipSuccess;
+  const bool use_wide = (kind == KernelKind::Wide || fr.packed == nullptr);
+  if (use_wide) {
+    if (fr.wide == nullptr) return hipErrorInvalidValue;
+    if ((e = ensure_lds(predict_fields_kernel<0>, lds)) != hipSuccess) return e;
+    const int grid = tile_grid(predict_fields_kernel<0>, lds, nrow, num_cus);
+    hipLaunchKernelGGL(predict_fields_kernel<0>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+  } else if (kind == KernelKind::Packed1) {
+    if ((e = ensure_lds(predict_fields_kernel<1>, lds)) != hipSuccess) return e;
+    const int grid = tile_grid(predict_fields_kernel<1>, lds, nrow, num_cus);
+    hipLaunchKernelGGL(predict_fields_kernel<1>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+  } else if (kind == KernelKind::Packed2) {
+    if ((e = ensure_lds(predict_fields_kernel<2>, lds)) != hipSuccess) return e;
+    const int grid = tile_grid(predict_fields_kernel<2>, lds, nrow, num_cus);
+    hipLaunchKernelGGL(predict_fields_kernel<2>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+  } else {
+    if ((e = ensure_lds(predict_fields_kernel<4>, lds)) != hipSuccess) return e;
+    const int grid = tile_grid(predict_fields_kernel<4>, lds, nrow, num_cus);
+    hipLaunchKernelGGL(predict_fields_kernel<4>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(scan_dense_kernel, dim3(grid_for(count / 4 + 1, 256, 8)), dim3(kBlock), 0, stream, data, count,
+                     missing, flags);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth_rows(uint32_t seed, int im, int jm, int km, uint64_t row_begin, uint64_t nrows, float* out,
+                             hipStream_t stream) {
+  if (nrows == 0) return hipSuccess;
+  hipLaunchKernelGGL(synth_rows_kernel, dim3(grid_for(nrows * OHX_NFEAT, 256, 16)), dim3(kBlock), 0, stream, seed, im,
+                     jm, km, row_begin, nrows, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth_field(uint32_t seed, int feature, int im, int jm, int km, float* out, hipStream_t stream) {
+  const uint64_t plane = (uint64_t)im * (uint64_t)jm;
+  const bool two_d = feature < 0 || ohx_feature_is_2d(feature);
+  const uint64_t total = two_d ? plane : plane * (uint64_t)km;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(synth_field_kernel, dim3(grid_for(total, 256, 16)), dim3(kBlock), 0, stream, seed, feature, im,
+                     jm, km, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_inject_missing(float* rows, uint64_t count, uint32_t seed, uint32_t rate_per_million, float missing,
+                                 hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(inject_missing_kernel, dim3(grid_for(count, 256, 16)), dim3(kBlock), 0, stream, rows, count, seed,
+                     rate_per_million, missing);
+  return hipGetLastError();
+}
+
+}  // namespace ohx

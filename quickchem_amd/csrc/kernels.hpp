@@ -1,0 +1,72 @@
+// Launchers for the gfx950 kernels (definitions in kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "flatten.hpp"
+
+namespace ohx {
+
+// Flag bits the kernels raise in a device word
+enum : uint32_t {
+  kFlagInfInput = 1u,  // an input value was +-inf while `missing` is finite
+};
+
+struct DeviceForest {
+  const PackedNode* packed = nullptr;   // may be null (booster does not qualify)
+  const WideNode* wide = nullptr;       // may be null until first needed
+  const uint32_t* roots = nullptr;
+  const int32_t* packed_orig_id = nullptr;
+  uint32_t num_trees = 0;
+  uint32_t num_feature = 0;
+  float base_score = 0.0f;
+};
+
+struct PredictArgs {
+  const float* rows = nullptr;  // [nrow][ncol] row-major (the reference's xx_carr(27,N))
+  uint64_t nrow = 0;
+  uint32_t ncol = 0;
+  float missing = 0.0f;
+  uint32_t tree_begin = 0, tree_end = 0;
+  float* out = nullptr;         // [nrow] margins, or [nrow][ntree] leaf ids when pred_leaf
+  bool pred_leaf = false;
+  uint32_t* flags = nullptr;    // device word, OR-ed with kFlag*
+};
+
+// 27 SoA fields of the MAPL state (OH_GridCompMod.F90:313-339), device pointers.
+struct FieldsArgs {
+  const float* field[32];
+  uint32_t is2d_mask = 0;      // bit f set => field f is (im,jm), else (im,jm,km)
+  uint32_t pl_feature = 1;     // feature index that is divided by 100 (Pa -> hPa), 0xFFFFFFFF for none
+  uint32_t nfield = 0;
+  int im = 0, jm = 0, km = 0, k1 = 0, k2 = 0;  // k1..k2 inclusive, 0-based
+  int src_k0 = 0;              // level the 3-D source arrays start at (0 = whole arrays, k1 = slab-only copies)
+  int out_k0 = 0;              // same for `out`
+  float missing = 0.0f;
+  uint32_t tree_begin = 0, tree_end = 0;
+  int apply_pow10 = 1;         // OH_ML = 10**pred (OH_GridCompMod.F90:369)
+  float scale = 1.0f;          // then * OHscale (OH_GridCompMod.F90:1569)
+  float* out = nullptr;        // (im,jm,km) array; only levels k1..k2 are written
+  float* margin_out = nullptr; // optional [N] raw margins in slab row order
+  uint32_t* flags = nullptr;
+};
+
+enum class KernelKind { Wide, Packed1, Packed2, Packed4 };
+
+const char* kernel_kind_name(KernelKind k);
+
+hipError_t launch_predict(KernelKind kind, const DeviceForest& forest, const PredictArgs& a, int num_cus,
+                          hipStream_t stream);
+hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& forest, const FieldsArgs& a, int num_cus,
+                                 hipStream_t stream);
+hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream);
+
+// synthetic inputs (synth_common.h), generated in HBM
+hipError_t launch_synth_rows(uint32_t seed, int im, int jm, int km, uint64_t row_begin, uint64_t nrows, float* out,
+                             hipStream_t stream);
+hipError_t launch_synth_field(uint32_t seed, int feature, int im, int jm, int km, float* out, hipStream_t stream);
+hipError_t launch_inject_missing(float* rows, uint64_t count, uint32_t seed, uint32_t rate_per_million, float missing,
+                                 hipStream_t stream);
+
+}  // namespace ohx

@@ -1,0 +1,150 @@
+"""Synthetic inputs of SURVEY.md §8(d): feature batches and the synthetic OH booster.
+
+The reference ships neither data nor a model (its models sit on NCCS paths,
+``OH_GridComp/OH_instance_OH.rc:17-20``), so tests and the benchmark draw both from
+``libohx_synth.so`` (host, g++) and from the device generator in ``libohxgb.so``;
+both compile the same ``csrc/synth_common.h`` and agree bit for bit.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SYNTH_LIB_PATH = os.path.join(_HERE, "lib", "libohx_synth.so")
+
+FEATURE_SEED = 20241108
+MODEL_SEED = 1060
+NFEAT = 27
+FEATURE_NAMES = ["LAT", "PL", "T", "NO2", "O3", "CH4", "CO", "ISOP", "ACET", "C2H6", "C3H8",
+                 "PRPE", "ALK4", "MP", "H2O2", "TAUCLWDN", "TAUCLIDN", "TAUCLIUP", "TAUCLWUP",
+                 "CLOUD", "QV", "GMISTRATO3", "ALBUV", "AODUP", "AODDN", "CH2O", "SZA"]
+IS2D = [n in ("LAT", "GMISTRATO3", "ALBUV", "SZA") for n in FEATURE_NAMES]
+PL_FEATURE = 1
+XX_MISS = -999.0             # OH_GridCompMod.F90:213
+
+# BASELINE.json configs: cubed-sphere C{n} is im = n, jm = 6n in MAPL's layout
+GRIDS: Dict[str, Tuple[int, int, int]] = {
+    "mock4x4": (4, 4, 72),
+    "C12": (12, 72, 72),
+    "C48": (48, 288, 72),
+    "C90": (90, 540, 72),
+    "C180": (180, 1080, 72),
+    "C360": (360, 2160, 72),
+    "C720L137": (720, 4320, 137),
+}
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SYNTH_LIB_PATH):
+            raise capi.OhxError(f"{SYNTH_LIB_PATH} is missing: run __graft_entry__.build()")
+        lib = C.CDLL(SYNTH_LIB_PATH)
+        lib.ohx_synth_last_error.restype = C.c_char_p
+        lib.ohx_synth_rows_cpu.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
+        lib.ohx_synth_field_cpu.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.ohx_synth_model.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                        C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.ohx_synth_free.argtypes = [C.c_void_p]
+        lib.ohx_model_convert.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_uint64)]
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise capi.OhxError(_load().ohx_synth_last_error().decode())
+
+
+def rows_cpu(grid: Tuple[int, int, int], row_begin: int, nrows: int, seed: int = FEATURE_SEED) -> np.ndarray:
+    """[nrows][27] float32, PL in hPa, rows m = i + im*(j + jm*k) (OH_GridCompMod.F90:309-345)."""
+    im, jm, km = grid
+    out = np.empty((nrows, NFEAT), dtype=np.float32)
+    _check(_load().ohx_synth_rows_cpu(seed, im, jm, km, row_begin, nrows, out.ctypes.data))
+    return out
+
+
+def field_cpu(grid: Tuple[int, int, int], feature: int, seed: int = FEATURE_SEED) -> np.ndarray:
+    """One MAPL field in Fortran order, returned as an [i,j(,k)]-indexed view.  feature -1 = TROPP (Pa); PL in Pa."""
+    im, jm, km = grid
+    two_d = feature < 0 or IS2D[feature]
+    flat = np.empty(im * jm * (1 if two_d else km), dtype=np.float32)
+    _check(_load().ohx_synth_field_cpu(seed, feature, im, jm, km, flat.ctypes.data))
+    return flat.reshape((jm, im)).T if two_d else flat.reshape((km, jm, im)).transpose(2, 1, 0)
+
+
+@dataclass
+class SynthModel:
+    image: np.ndarray          # uint8 file image (legacy binary or JSON)
+    num_trees: int
+    num_nodes: int
+    num_leaves: int
+    max_depth: int
+    mean_path: float           # internal nodes visited per row per tree, over the growth sample
+
+
+def _take(ptr: C.c_void_p, n: int) -> np.ndarray:
+    lib = _load()
+    buf = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    lib.ohx_synth_free(ptr)
+    return buf
+
+
+def make_model(num_trees: int = 100, max_depth: int = 18, sample_log2: int = 20, min_leaf: int = 8,
+               grid: Tuple[int, int, int] = GRIDS["C90"], model_seed: int = MODEL_SEED,
+               feature_seed: int = FEATURE_SEED, base_score: float = -13.0, leaf_sigma: float = 0.05,
+               fmt: str = "binary") -> SynthModel:
+    """The synthetic OH booster: `num_trees` trees of depth <= `max_depth`, 27 features,
+    grown on 2**sample_log2 cells of `grid`, thresholds = sampled feature values."""
+    lib = _load()
+    out, n = C.c_void_p(), C.c_uint64()
+    stats = (C.c_uint64 * 4)()
+    im, jm, km = grid
+    _check(lib.ohx_synth_model(model_seed, num_trees, max_depth, sample_log2, min_leaf, feature_seed, im, jm, km,
+                               base_score, leaf_sigma, 1 if fmt == "json" else 0, C.byref(out), C.byref(n), stats))
+    denom = float((1 << sample_log2) * max(num_trees, 1))
+    return SynthModel(_take(out, n.value), num_trees, int(stats[0]), int(stats[1]), int(stats[2]),
+                      float(stats[3]) / denom)
+
+
+def convert_model(image, fmt: str) -> np.ndarray:
+    """Legacy binary <-> JSON through the product's own reader and writer (host logic)."""
+    lib = _load()
+    src = np.frombuffer(bytes(image), dtype=np.uint8) if not isinstance(image, np.ndarray) else image
+    out, n = C.c_void_p(), C.c_uint64()
+    _check(lib.ohx_model_convert(src.ctypes.data, src.nbytes, 1 if fmt == "json" else 0, C.byref(out), C.byref(n)))
+    return _take(out, n.value)
+
+
+# ---- device generators (torch tensors in HBM; libohxgb.so) ----
+
+def rows_device(grid: Tuple[int, int, int], row_begin: int, nrows: int, out, seed: int = FEATURE_SEED,
+                stream: int = 0) -> None:
+    """Fill torch tensor `out` ([nrows][27] float32, on the GPU) with rows row_begin.."""
+    lib = capi.load_library()
+    im, jm, km = grid
+    assert out.is_contiguous() and out.numel() == nrows * NFEAT
+    capi.check(lib, lib.OHXSynthRowsDevice(seed, im, jm, km, row_begin, nrows, out.data_ptr(), stream or None))
+
+
+def field_device(grid: Tuple[int, int, int], feature: int, out, seed: int = FEATURE_SEED, stream: int = 0) -> None:
+    lib = capi.load_library()
+    im, jm, km = grid
+    capi.check(lib, lib.OHXSynthFieldDevice(seed, feature, im, jm, km, out.data_ptr(), stream or None))
+
+
+def inject_missing_device(rows, rate_per_million: int, missing: float = XX_MISS, seed: int = 7, stream: int = 0) -> None:
+    lib = capi.load_library()
+    capi.check(lib, lib.OHXInjectMissingDevice(rows.data_ptr(), rows.numel(), seed, rate_per_million, missing,
+                                               stream or None))

@@ -1,0 +1,65 @@
+"""The N > 1 path on CPU: world_size 2 over gloo.  The per-rank compute is stood in for by
+the oracle; what is under test is the sharding and the reassembly bench.py uses."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from quickchem_amd import shard, synth
+from tests import helpers
+
+
+def test_row_shards_tile_the_batch():
+    for n_total in (0, 1, 7, 64, 55_987_200, 426_124_800):
+        for world in (1, 2, 3, 4, 8):
+            pos = 0
+            sizes = []
+            for r in range(world):
+                row0, n = shard.row_shard(n_total, world, r)
+                assert row0 == pos
+                pos += n
+                sizes.append(n)
+            assert pos == n_total and max(sizes) - min(sizes) <= 1
+    assert shard.row_shard(55_987_200, 8, 3) == (3 * 6_998_400, 6_998_400)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, image_path, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grid = synth.GRIDS["C12"]
+        image = np.fromfile(image_path, dtype=np.uint8)
+        row0, n = shard.row_shard(n_total, world, rank)
+        rows = synth.rows_cpu(grid, row0, n)                      # each rank generates only its shard
+        local = torch.from_numpy(helpers.oracle_predict(image, rows, synth.XX_MISS))
+        full = torch.empty(n_total, dtype=torch.float32)
+        shard.all_gather_rows(full, local, n_total, world, n_total % world == 0)
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [4096, 4099])
+def test_two_ranks_reassemble_the_field(tmp_path, small_model, n_total):
+    image_path = tmp_path / "m.bin"
+    small_model.image.tofile(image_path)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_total, str(image_path), str(tmp_path)), nprocs=2, join=True)
+    rows = synth.rows_cpu(synth.GRIDS["C12"], 0, n_total)
+    want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npy")
+        assert np.array_equal(helpers.bits(got), helpers.bits(want))

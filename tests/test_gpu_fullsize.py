@@ -1,0 +1,60 @@
+"""BASELINE.json's full sizes on the GPU, through size-independent properties (the oracle would
+take minutes at these sizes): kernels of different design agree bit for bit, shards concatenate
+to the whole, and a random sample is checked against the oracle."""
+import numpy as np
+import pytest
+
+from quickchem_amd import capi, synth
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    return synth.make_model()          # 100 trees, depth <= 18, 2**20-row sample
+
+
+def _predict_dev(torch, booster, rows, kernel):
+    booster.set_param("ohx_kernel", kernel)
+    d = capi.DMatrix(device_ptr=rows.data_ptr(), nrow=rows.shape[0], ncol=27, missing=synth.XX_MISS)
+    out = torch.empty(rows.shape[0], dtype=torch.float32, device="cuda")
+    booster.predict_device(d, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    booster.check()
+    d.free()
+    return out
+
+
+@pytest.mark.parametrize("gridname,shard", [("C48", None), ("C180", None), ("C360", 8)])
+def test_full_size_properties(full_model, gridname, shard):
+    import torch
+    torch.cuda.set_device(0)
+    grid = synth.GRIDS[gridname]
+    n = grid[0] * grid[1] * grid[2]
+    if shard:                               # C360: one of the 8 contiguous row shards (6 998 400 rows)
+        n //= shard
+    row0 = 3 * n if shard else 0
+    rows = torch.empty((n, 27), dtype=torch.float32, device="cuda")
+    synth.rows_device(grid, row0, n, rows)
+    synth.inject_missing_device(rows, 100)                     # 1e-4 of the entries: -999.0 or NaN
+    booster = capi.Booster(model_buffer=full_model.image)
+    a = _predict_dev(torch, booster, rows, "packed4")
+    b = _predict_dev(torch, booster, rows, "wide")             # different node format, no LDS tile, 1 chain
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    c = _predict_dev(torch, booster, rows, "packed1")
+    assert torch.equal(a.view(torch.int32), c.view(torch.int32))
+    # shards concatenate to the whole (what the 8-GPU run relies on)
+    cut = (n // 3) // 64 * 64 + 17
+    parts = [_predict_dev(torch, booster, rows[:cut], "packed4"), _predict_dev(torch, booster, rows[cut:], "packed4")]
+    assert torch.equal(torch.cat(parts).view(torch.int32), a.view(torch.int32))
+    # permutation equivariance on a block
+    perm = torch.randperm(100_000, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    sub = rows[:100_000][perm].contiguous()
+    assert torch.equal(_predict_dev(torch, booster, sub, "packed4").view(torch.int32), a[:100_000][perm].view(torch.int32))
+    # a random sample against the oracle, on the very same bytes
+    idx = torch.randint(0, n, (50_000,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    sample = rows[idx].cpu().numpy()
+    want = helpers.oracle_predict(full_model.image, sample, synth.XX_MISS)
+    assert np.array_equal(helpers.bits(a[idx].cpu().numpy()), helpers.bits(want))
+    assert torch.isfinite(a).all() and -16 < float(a.min()) and float(a.max()) < -10

@@ -1,0 +1,276 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI (GPU).
+
+Bit-exact on the raw margin (xx_pred) everywhere; `10**pred` within 2 ulp of the
+oracle's powf (10.0**x is libm-specific)."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from quickchem_amd import capi, oh_predict, synth
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = ["wide", "packed1", "packed2", "packed4"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def gpu_predict(image, rows, missing, kernel="auto", option_mask=0, ntree_limit=0, params=None):
+    b = capi.Booster(model_buffer=image)
+    b.set_param("ohx_kernel", kernel)
+    for k, v in (params or {}).items():
+        b.set_param(k, v)
+    d = capi.DMatrix(rows, missing=missing)
+    out = b.predict(d, option_mask=option_mask, ntree_limit=ntree_limit)
+    d.free()
+    b.free()
+    return out
+
+
+def with_missing(rows, rate, seed=3):
+    rows = rows.copy()
+    rng = np.random.default_rng(seed)
+    mask = rng.random(rows.shape) < rate
+    rows[mask] = np.where(rng.random(int(mask.sum())) < 0.5, np.float32(synth.XX_MISS), np.float32(np.nan))
+    return rows
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_hand_forest_golden(torch_cuda, kernel):
+    cases, rows = helpers.load_hand_cases()
+    image = open(os.path.join(helpers.GOLDEN, "hand_forest.json"), "rb").read()
+    miss = cases["missing"]
+    assert np.array_equal(gpu_predict(image, rows, miss, kernel), np.float32(cases["margin"]))
+    assert np.array_equal(gpu_predict(image, rows, miss, kernel, ntree_limit=2), np.float32(cases["margin_ntree_limit_2"]))
+    assert np.array_equal(gpu_predict(image, rows, miss, kernel, ntree_limit=3), np.float32(cases["margin_ntree_limit_3"]))
+    assert np.array_equal(gpu_predict(image, rows, miss, kernel, option_mask=1), np.float32(cases["margin"]))
+    leaves = gpu_predict(image, rows, miss, kernel, option_mask=16).reshape(len(rows), -1)
+    assert np.array_equal(leaves, np.float32(cases["leaf_index"]))
+    assert np.array_equal(gpu_predict(image, np.float32(cases["rows_2col"]), miss, kernel), np.float32(cases["margin_2col"]))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_config1_golden(torch_cuda, deep_model, kernel):
+    g = json.load(open(os.path.join(helpers.GOLDEN, "mock4x4_T100.json")))
+    grid = tuple(g["grid"])
+    rows = synth.rows_cpu(grid, 0, grid[0] * grid[1] * grid[2])
+    got = gpu_predict(deep_model.image, rows, synth.XX_MISS, kernel)
+    assert np.array_equal(helpers.bits(got), np.array(g["margin_bits"], dtype=np.uint32))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("nrows", [1, 63, 64, 65, 1000, 62208])
+def test_rows_vs_oracle_ragged_sizes(torch_cuda, small_model, kernel, nrows):
+    rows = synth.rows_cpu(synth.GRIDS["C12"], 0, nrows)
+    want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
+    got = gpu_predict(small_model.image, rows, synth.XX_MISS, kernel)
+    assert np.array_equal(helpers.bits(got), helpers.bits(want))
+
+
+def test_empty_matrix(torch_cuda, small_model):
+    got = gpu_predict(small_model.image, np.zeros((0, 27), dtype=np.float32), synth.XX_MISS)
+    assert got.shape == (0,)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("missing", [synth.XX_MISS, float("nan")])
+def test_missing_values_vs_oracle(torch_cuda, deep_model, kernel, missing):
+    rows = with_missing(synth.rows_cpu(synth.GRIDS["C12"], 5000, 20000), 0.01)
+    want = helpers.oracle_predict(deep_model.image, rows, missing)
+    got = gpu_predict(deep_model.image, rows, missing, kernel)
+    assert np.array_equal(helpers.bits(got), helpers.bits(want))
+
+
+@pytest.mark.parametrize("kernel", ["wide", "packed4"])
+def test_ntree_limit_and_leaf_indices(torch_cuda, small_model, kernel):
+    rows = with_missing(synth.rows_cpu(synth.GRIDS["C12"], 0, 3000), 0.005)
+    for lim in (1, 7, 19, 20, 500):
+        want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS, ntree_limit=lim)
+        got = gpu_predict(small_model.image, rows, synth.XX_MISS, kernel, ntree_limit=lim)
+        assert np.array_equal(helpers.bits(got), helpers.bits(want)), lim
+    want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS, option_mask=16)
+    got = gpu_predict(small_model.image, rows, synth.XX_MISS, kernel, option_mask=16)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("params", [{"ohx_line_slots": 0}, {"ohx_top_levels": 1}, {"ohx_top_levels": 4, "ohx_line_slots": 32},
+                                    {"ohx_top_levels": 12, "ohx_min_chunk": 2}])
+def test_layout_does_not_change_results(torch_cuda, deep_model, params):
+    rows = synth.rows_cpu(synth.GRIDS["C12"], 0, 8192)
+    want = helpers.oracle_predict(deep_model.image, rows, synth.XX_MISS)
+    got = gpu_predict(deep_model.image, rows, synth.XX_MISS, "packed4", params=params)
+    assert np.array_equal(helpers.bits(got), helpers.bits(want))
+
+
+def test_fewer_columns_than_features(torch_cuda, small_model):
+    rows = synth.rows_cpu(synth.GRIDS["C12"], 0, 4096)[:, :20].copy()
+    want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
+    for kernel in ("wide", "packed4"):
+        got = gpu_predict(small_model.image, rows, synth.XX_MISS, kernel)
+        assert np.array_equal(helpers.bits(got), helpers.bits(want))
+
+
+def test_error_paths(torch_cuda, small_model):
+    rows = synth.rows_cpu(synth.GRIDS["C12"], 0, 256)
+    b = capi.Booster(model_buffer=small_model.image)
+    # more columns than the booster has features
+    wide_rows = np.concatenate([rows, rows[:, :3]], axis=1)
+    with pytest.raises(capi.OhxError, match="Number of columns"):
+        b.predict(capi.DMatrix(wide_rows, missing=synth.XX_MISS))
+    # inf in the data is refused at matrix creation, as xgboost 1.6.0 does
+    bad = rows.copy()
+    bad[17, 4] = -np.inf
+    with pytest.raises(capi.OhxError, match="inf"):
+        capi.DMatrix(bad, missing=synth.XX_MISS)
+    # ... unless missing itself is inf
+    capi.DMatrix(bad, missing=float("inf")).free()
+    # unsupported outputs
+    d = capi.DMatrix(rows, missing=synth.XX_MISS)
+    with pytest.raises(capi.OhxError, match="option_mask"):
+        b.predict(d, option_mask=4)
+    # a booster without a model
+    with pytest.raises(capi.OhxError, match="no model"):
+        capi.Booster().predict(d)
+    # device-resident path: inf is caught by the kernel and surfaced by check()
+    t = torch_cuda.from_numpy(bad).cuda()
+    dd = capi.DMatrix(device_ptr=t.data_ptr(), nrow=bad.shape[0], ncol=27, missing=synth.XX_MISS)
+    out = torch_cuda.empty(bad.shape[0], dtype=torch_cuda.float32, device="cuda")
+    b.predict_device(dd, out.data_ptr())
+    with pytest.raises(capi.OhxError, match="inf"):
+        b.check()
+    b.check()                                   # the flag is cleared once reported
+
+
+def test_dmatrix_file_round_trip(torch_cuda, tmp_path, small_model):
+    rows = synth.rows_cpu(synth.GRIDS["C12"], 0, 500)
+    d = capi.DMatrix(rows, missing=synth.XX_MISS)
+    assert (d.num_row, d.num_col) == (500, 27)
+    p = str(tmp_path / "rows.ohxdmat")
+    d.save_binary(p)
+    d2 = capi.DMatrix.from_file(p)
+    b = capi.Booster(model_buffer=small_model.image)
+    assert np.array_equal(b.predict(d), b.predict(d2))
+    csv = tmp_path / "rows.csv"
+    np.savetxt(csv, rows[:50], delimiter=",", fmt="%.9g")
+    d3 = capi.DMatrix.from_file(str(csv))
+    assert np.array_equal(b.predict(d3), b.predict(capi.DMatrix(rows[:50], missing=float("nan"))))
+
+
+def test_device_generator_matches_host_generator(torch_cuda):
+    torch = torch_cuda
+    grid = synth.GRIDS["C12"]
+    n = grid[0] * grid[1] * grid[2]
+    dev = torch.empty((n, 27), dtype=torch.float32, device="cuda")
+    synth.rows_device(grid, 0, n, dev)
+    torch.cuda.synchronize()
+    host = synth.rows_cpu(grid, 0, n)
+    got = dev.cpu().numpy()
+    for f in range(27):
+        assert np.array_equal(helpers.bits(got[:, f]), helpers.bits(host[:, f])), synth.FEATURE_NAMES[f]
+    # a shard generated on its own equals the same rows of the whole
+    part = torch.empty((1000, 27), dtype=torch.float32, device="cuda")
+    synth.rows_device(grid, 40000, 1000, part)
+    assert np.array_equal(part.cpu().numpy(), host[40000:41000])
+    for f in (-1, 0, 1, 15, 26):
+        two_d = f < 0 or synth.IS2D[f]
+        t = torch.empty(grid[0] * grid[1] * (1 if two_d else grid[2]), dtype=torch.float32, device="cuda")
+        synth.field_device(grid, f, t)
+        want = helpers.fortran_flat(synth.field_cpu(grid, f)).ravel()
+        assert np.array_equal(helpers.bits(t.cpu().numpy()), helpers.bits(want)), f
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dynamic", [True, False])
+def test_fused_fields_vs_oracle(torch_cuda, deep_model, kernel, dynamic):
+    """OHXBoosterPredictFields against the oracle's restatement of predict_OH_with_XGB's RUN section."""
+    grid = synth.GRIDS["C12"]
+    pl, tropp, fields = helpers.synth_state(grid)
+    oh_ref, margin_ref, k1, k2 = helpers.oracle_predict_oh(deep_model.image, pl, tropp, fields, dynamic)
+    p = oh_predict.OHPredictor()
+    p.xx_bst = capi.Booster(model_buffer=deep_model.image)
+    p.xx_bst.set_param("ohx_kernel", kernel)
+    p.first_time = False
+    oh = np.zeros(grid, dtype=np.float32)
+    margins = []
+    rc = p.predict_OH_with_XGB("unused", *grid, dynamic, 4000.0, pl, tropp, oh_predict.OHBoostInputData(fields), oh,
+                               mode="fused", margin_out=margins)
+    assert rc == 0
+    assert np.array_equal(helpers.bits(margins[0]), helpers.bits(margin_ref))          # bit-exact traversal + sum
+    assert np.all(oh[:, :, :k1 - 1] == 0)
+    assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2       # 10**x, tolerance 2 ulp
+
+
+@pytest.mark.parametrize("mode", ["compat", "fused"])
+def test_python_mirror_loads_model_file_once(torch_cuda, tmp_path, small_model, mode):
+    """predict_OH_with_XGB mirror end to end, incl. ONE_TIME_SETUP and the SAVE'd booster (:242-271)."""
+    grid = synth.GRIDS["mock4x4"]
+    pl, tropp, fields = helpers.synth_state(grid)
+    mf = tmp_path / "OH_model.bin"
+    mf.write_bytes(small_model.image.tobytes())
+    p = oh_predict.OHPredictor()
+    oh = np.zeros(grid, dtype=np.float32)
+    margins = []
+    assert p.predict_OH_with_XGB(str(mf) + "   ", *grid, True, 4000.0, pl, tropp, oh_predict.OHBoostInputData(fields), oh,
+                                 mode=mode, margin_out=margins) == 0
+    oh_ref, margin_ref, k1, k2 = helpers.oracle_predict_oh(small_model.image, pl, tropp, fields, True)
+    assert np.array_equal(helpers.bits(margins[0]), helpers.bits(margin_ref))
+    assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2
+    # later calls ignore the file name, as the reference does (first_time, :209,269)
+    oh2 = np.zeros(grid, dtype=np.float32)
+    assert p.predict_OH_with_XGB("/nonexistent", *grid, True, 4000.0, pl, tropp, oh_predict.OHBoostInputData(fields), oh2,
+                                 mode=mode) == 0
+    assert np.array_equal(oh, oh2)
+
+
+@pytest.mark.parametrize("mode", ["compat", "fused"])
+def test_fortran_host_on_the_gpu(torch_cuda, tmp_path, small_model, mode):
+    """The Fortran predict_OH_with_XGB linked against libohxgb.so: same state, same answers as the
+    same Fortran linked against the oracle (bit-exact OH_ML in compat mode: both use flang's 10.0**x)."""
+    grid = synth.GRIDS["C12"]
+    pl, tropp, fields = helpers.synth_state(grid)
+    state, model = tmp_path / "state.bin", tmp_path / "oh.model"
+    helpers.write_state_file(state, pl, tropp, fields, True, ohscale=0.85)
+    model.write_bytes(small_model.image.tobytes())
+    out_g, out_c = tmp_path / "gpu.bin", tmp_path / "cpu.bin"
+    r = helpers.run_driver(helpers.DRIVER_HIP, state, model, out_g, mode)
+    assert r.returncode == 0, r.stdout
+    r = helpers.run_driver(helpers.DRIVER_ORACLE, state, model, out_c, "compat")
+    assert r.returncode == 0, r.stdout
+    rc, k1, k2, oh_g, _ = helpers.read_driver_output(out_g, *grid)
+    rc2, k1c, k2c, oh_c, _ = helpers.read_driver_output(out_c, *grid)
+    assert rc == 0 and rc2 == 0 and (k1, k2) == (k1c, k2c)
+    if mode == "compat":
+        assert np.array_equal(helpers.bits(oh_g), helpers.bits(oh_c))
+    else:
+        assert np.all(oh_g[:, :, :k1 - 1] == 0)
+        assert helpers.ulp_diff(oh_g[:, :, k1 - 1:], oh_c[:, :, k1 - 1:]).max() <= 2
+
+
+def test_reference_binding_module_drives_the_gpu(torch_cuda, tmp_path, small_model):
+    """Drop-in: the reference's own xgb_fortran_api.F90 (compiled in place into oracle/_ref) making the
+    reference's call sequence against libohxgb.so."""
+    if not os.path.exists(helpers.DROPIN_HIP):
+        pytest.skip("oracle/_ref not built")
+    rows = synth.rows_cpu(synth.GRIDS["C12"], 0, 62208)
+    rf, mf, pf = tmp_path / "rows.bin", tmp_path / "oh.model", tmp_path / "pred.bin"
+    with open(rf, "wb") as f:
+        f.write(struct.pack("<qq", rows.shape[0], rows.shape[1]))
+        f.write(rows.tobytes())
+    mf.write_bytes(small_model.image.tobytes())
+    r = helpers.run_driver(helpers.DROPIN_HIP, rf, mf, pf)
+    assert r.returncode == 0, r.stdout
+    raw = pf.read_bytes()
+    n, = struct.unpack_from("<q", raw, 0)
+    pred = np.frombuffer(raw, dtype="<f4", count=n, offset=8)
+    want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
+    assert np.array_equal(helpers.bits(pred), helpers.bits(want))

@@ -1,0 +1,116 @@
+"""Host logic of XGBoosterLoadModel/SaveModel: legacy binary <-> JSON (CPU)."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import xgb_oracle as O
+from quickchem_amd import capi, synth
+from tests import helpers
+
+
+def test_binary_json_round_trip(small_model):
+    js = synth.convert_model(small_model.image, "json")
+    back = synth.convert_model(js, "binary")
+    assert np.array_equal(back, small_model.image)
+    doc = json.loads(js.tobytes())
+    assert doc["learner"]["gradient_booster"]["name"] == "gbtree"
+    assert int(doc["learner"]["learner_model_param"]["num_feature"]) == 27
+    assert len(doc["learner"]["gradient_booster"]["model"]["trees"]) == small_model.num_trees
+
+
+def test_json_and_binary_predict_the_same(small_model):
+    rows = synth.rows_cpu(synth.GRIDS["C12"], 0, 2048)
+    js = synth.convert_model(small_model.image, "json")
+    a = O.predict(O.load_model(small_model.image.tobytes()), rows, missing=synth.XX_MISS)
+    b = O.predict(O.load_model(js.tobytes()), rows, missing=synth.XX_MISS)
+    assert np.array_equal(helpers.bits(a), helpers.bits(b))
+
+
+def test_binary_layout_sizes(small_model):
+    """136-byte learner param, two length-prefixed names, 160-byte gbtree param, then per tree
+    148 + 36 * num_nodes bytes, then tree_info."""
+    img = small_model.image.tobytes()
+    assert img[:4] == b"binf"
+    off = 4 + 136
+    n, = struct.unpack_from("<Q", img, off)
+    assert img[off + 8:off + 8 + n] == b"reg:squarederror"
+    off += 8 + n
+    n, = struct.unpack_from("<Q", img, off)
+    assert img[off + 8:off + 8 + n] == b"gbtree"
+    off += 8 + n
+    num_trees, = struct.unpack_from("<i", img, off)
+    assert num_trees == small_model.num_trees
+    off += 160
+    total = 0
+    for _ in range(num_trees):
+        num_nodes = struct.unpack_from("<37i", img, off)[1]
+        total += num_nodes
+        off += 148 + 36 * num_nodes
+    assert total == small_model.num_nodes
+    assert off + 4 * num_trees == len(img)
+
+
+def test_file_round_trip_through_the_abi(tmp_path, small_model):
+    """XGBoosterLoadModel / XGBoosterSaveModel need no GPU: host logic only."""
+    p_bin, p_json, p_bin2 = tmp_path / "m.model", tmp_path / "m.json", tmp_path / "m2.bin"
+    p_bin.write_bytes(small_model.image.tobytes())
+    b = capi.Booster(str(p_bin))
+    b.save_model(str(p_json))
+    b2 = capi.Booster(str(p_json))
+    b2.save_model(str(p_bin2))
+    assert p_bin2.read_bytes() == small_model.image.tobytes()
+    info = b2.info()
+    assert info["num_trees"] == small_model.num_trees and info["num_nodes"] == small_model.num_nodes
+    assert info["num_slots"] >= info["num_nodes"] and info["packed"] == 1 and info["num_feature"] == 27
+
+
+@pytest.mark.parametrize("mutation", ["truncate", "bad_child", "ubj", "garbage_json", "nonadjacent"])
+def test_malformed_models_fail_loudly(tmp_path, small_model, mutation):
+    img = bytearray(small_model.image.tobytes())
+    path = tmp_path / "m.model"
+    if mutation == "truncate":
+        img = img[:len(img) // 2]
+    elif mutation == "bad_child":
+        # first tree, root node: cleft far out of range
+        off = 4 + 136 + 8 + 16 + 8 + 6 + 160 + 148
+        struct.pack_into("<i", img, off + 4, 10**8)
+        struct.pack_into("<i", img, off + 8, 10**8 + 1)
+    elif mutation == "nonadjacent":
+        off = 4 + 136 + 8 + 16 + 8 + 6 + 160 + 148
+        l, r = struct.unpack_from("<ii", img, off + 4)
+        struct.pack_into("<ii", img, off + 4, r, l)          # right == left - 1
+    elif mutation == "ubj":
+        path = tmp_path / "m.ubj"
+    elif mutation == "garbage_json":
+        path = tmp_path / "m.json"
+        img = bytearray(b'{"learner": {"oops": 1}}')
+    path.write_bytes(bytes(img))
+    b = capi.Booster()
+    with pytest.raises(capi.OhxError):
+        b.load_model(str(path))
+
+
+def test_missing_file_and_unloaded_booster(tmp_path):
+    b = capi.Booster()
+    with pytest.raises(capi.OhxError, match="cannot open"):
+        b.load_model(str(tmp_path / "nope.model"))
+    with pytest.raises(capi.OhxError, match="no model"):
+        b.save_model(str(tmp_path / "x.model"))
+
+
+def test_layout_parameters_change_slots_not_nodes(deep_model):
+    b = capi.Booster(model_buffer=deep_model.image)
+    base = b.info()
+    b.set_param("ohx_line_slots", 0)
+    bfs = b.info()
+    assert bfs["num_nodes"] == base["num_nodes"] == deep_model.num_nodes
+    assert bfs["num_slots"] == bfs["num_nodes"]                 # breadth-first only: no padding
+    assert base["num_slots"] < 1.35 * base["num_nodes"]         # line packing wastes little
+    assert base["max_depth"] == deep_model.max_depth == 18
+    b.set_param("ohx_kernel", "wide")
+    assert b.info()["packed"] == 0 and b.info()["node_bytes"] == 16 * bfs["num_slots"]
+    with pytest.raises(capi.OhxError):
+        b.set_param("ohx_kernel", "nope")
