@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--sample-log2", type=int, default=20)
     ap.add_argument("--top-levels", type=int, default=None)
     ap.add_argument("--line-slots", type=int, default=None)
+    ap.add_argument("--param", action="append", default=[], help="extra XGBoosterSetParam name=value (repeatable)")
     ap.add_argument("--missing-ppm", type=int, default=0, help="inject -999.0/NaN at this rate per million entries")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--shuffle", action="store_true", help="permute the rows (destroys spatial coherence)")
@@ -111,6 +112,9 @@ def main():
         booster.set_param("ohx_top_levels", args.top_levels)
     if args.line_slots is not None:
         booster.set_param("ohx_line_slots", args.line_slots)
+    for kv in args.param:
+        name, _, val = kv.partition("=")
+        booster.set_param(name, val)
     t_model = time.perf_counter() - t0
 
     # ---- the batch: this rank's contiguous row shard, generated in HBM ----
@@ -199,7 +203,7 @@ def main():
                           "node_slots": info["num_slots"], "node_bytes": info["node_bytes"],
                           "mean_path": round(model.mean_path, 3), "seed": synth.MODEL_SEED,
                           "build_s": round(t_model, 2)},
-                "kernel": args.kernel, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle),
+                "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle),
                 "parallelism": f"rows{world}",
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

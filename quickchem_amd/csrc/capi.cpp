@@ -144,6 +144,7 @@ struct BoosterObj {
   LayoutParams layout;
   std::string kernel_name = "auto";
   int device_pref = -1;
+  LaunchTuning tune;
   // device state, built lazily at the first compute call
   bool uploaded = false;
   DeviceInfo dev;
@@ -151,6 +152,10 @@ struct BoosterObj {
   bool packed_ok = false;
   DevBuf<PackedNode> d_packed;
   DevBuf<WideNode> d_wide;
+  DevBuf<SuperNode> d_super;
+  DevBuf<uint32_t> d_super_base;
+  bool super_ok = false;
+  uint64_t super_slots = 0;
   DevBuf<uint32_t> d_roots;
   DevBuf<uint32_t> d_flags;
   DevBuf<float> d_pred;
@@ -173,16 +178,27 @@ BoosterObj* as_booster(BoosterHandle h) {
 
 KernelKind pick_kernel(const BoosterObj& b) {
   const std::string& k = b.kernel_name;
-  if (!b.packed_ok || k == "wide") return KernelKind::Wide;
+  if (k == "wide") return KernelKind::Wide;
+  if (b.super_ok) {
+    if (k == "super1") return KernelKind::Super1;
+    if (k == "super4") return KernelKind::Super4;
+    if (k == "super2" || k == "auto") return KernelKind::Super2;
+  }
+  if (!b.packed_ok) return KernelKind::Wide;
   if (k == "packed1") return KernelKind::Packed1;
-  if (k == "packed2") return KernelKind::Packed2;
-  return KernelKind::Packed4;
+  if (k == "packed4") return KernelKind::Packed4;
+  return KernelKind::Packed2;
 }
+
+bool wants_super(const std::string& k) { return k == "auto" || k == "super1" || k == "super2" || k == "super4"; }
 
 void invalidate_device_state(BoosterObj& b) {
   b.uploaded = false;
   b.d_packed.release();
   b.d_wide.release();
+  b.d_super.release();
+  b.d_super_base.release();
+  b.super_ok = false;
   b.d_roots.release();
 }
 
@@ -202,7 +218,16 @@ void ensure_uploaded(BoosterObj& b) {
   b.placement = place_forest(b.forest, b.layout);
   b.packed_ok = packed_format_fits(b.forest, b.placement);
   b.d_roots.upload(b.placement.roots);
-  if (b.packed_ok) {
+  if (wants_super(b.kernel_name)) {
+    SuperForest sf;
+    b.super_ok = emit_super(b.forest, &sf) && sf.nodes.size() * sizeof(SuperNode) < 0xFFFFFFF0ull;
+    if (b.super_ok) {
+      b.super_slots = sf.nodes.size();
+      b.d_super.upload(sf.nodes);
+      b.d_super_base.upload(sf.tree_base);
+    }
+  }
+  if (b.packed_ok && !(b.super_ok && wants_super(b.kernel_name))) {
     std::vector<PackedNode> packed = emit_packed(b.forest, b.placement, nullptr);
     b.d_packed.upload(packed);
   }
@@ -217,6 +242,10 @@ DeviceForest device_forest(const BoosterObj& b) {
   d.packed = b.d_packed.p;
   d.wide = b.d_wide.p;
   d.roots = b.d_roots.p;
+  d.super = b.d_super.p;
+  d.super_base = b.d_super_base.p;
+  d.packed_bytes = (uint32_t)(b.d_packed.n * sizeof(PackedNode));
+  d.super_bytes = (uint32_t)(b.d_super.n * sizeof(SuperNode));
   d.num_trees = (uint32_t)b.forest.trees.size();
   d.num_feature = b.forest.num_feature;
   d.base_score = b.forest.base_score;
@@ -288,7 +317,7 @@ void launch_predict_checked(BoosterObj& b, const DMatrixObj& d, int option_mask,
   a.out = d_out;
   a.pred_leaf = pred_leaf;
   a.flags = b.d_flags.p;
-  HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream));
+  HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, b.tune));
 }
 
 }  // namespace
@@ -501,8 +530,10 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
   if (name == nullptr || value == nullptr) throw OhxError("XGBoosterSetParam: NULL argument");
   const std::string n(name), v(value);
   if (n == "ohx_kernel") {
-    if (v != "auto" && v != "wide" && v != "packed1" && v != "packed2" && v != "packed4")
-      throw OhxError("ohx_kernel must be one of auto, wide, packed1, packed2, packed4");
+    if (v != "auto" && v != "wide" && v != "packed1" && v != "packed2" && v != "packed4" && v != "super1" &&
+        v != "super2" && v != "super4")
+      throw OhxError("ohx_kernel must be one of auto, wide, packed1, packed2, packed4, super1, super2, super4");
+    if (v != b->kernel_name) invalidate_device_state(*b);
     b->kernel_name = v;
   } else if (n == "ohx_top_levels") {
     int k = atoi(value);
@@ -519,6 +550,12 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     if (k < 2 || k > 1024) throw OhxError("ohx_min_chunk must be in 2..1024");
     if (k != b->layout.min_chunk) invalidate_device_state(*b);
     b->layout.min_chunk = k;
+  } else if (n == "ohx_launches_per_residency") {
+    int k = atoi(value);
+    if (k < 0 || k > 1000000) throw OhxError("ohx_launches_per_residency must be >= 0");
+    b->tune.launches_per_residency = k;
+  } else if (n == "ohx_xcd_remap") {
+    b->tune.xcd_remap = atoi(value) != 0;
   } else if (n == "ohx_device") {
     int k = atoi(value);
     if (k != b->device_pref) invalidate_device_state(*b);
@@ -674,13 +711,25 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
     packed_ok = packed_format_fits(b->forest, local);
   }
   const bool packed_used = packed_ok && b->kernel_name != "wide";
+  bool super_used = false;
+  uint64_t super_slots = b->super_slots;
+  if (wants_super(b->kernel_name)) {
+    if (b->uploaded) {
+      super_used = b->super_ok;
+    } else {
+      SuperForest sf;
+      super_used = emit_super(b->forest, &sf);
+      super_slots = sf.nodes.size();
+    }
+  }
   info[0] = b->forest.trees.size();
   info[1] = p->real_nodes;
-  info[2] = p->num_slots;
-  info[3] = p->num_slots * (packed_used ? sizeof(PackedNode) : sizeof(WideNode));
+  info[2] = super_used ? super_slots : p->num_slots;
+  info[3] = super_used ? super_slots * sizeof(SuperNode)
+                       : p->num_slots * (packed_used ? sizeof(PackedNode) : sizeof(WideNode));
   info[4] = (bst_ulong)p->max_depth;
   info[5] = b->forest.num_feature;
-  info[6] = packed_used ? 1 : 0;
+  info[6] = super_used ? 2 : (packed_used ? 1 : 0);
   info[7] = 0;
   API_END();
 }

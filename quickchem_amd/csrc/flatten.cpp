@@ -97,6 +97,7 @@ Placement place_forest(const Forest& f, const LayoutParams& lp) {
 }
 
 bool packed_format_fits(const Forest& f, const Placement& p) {
+  // < 2**26 slots also keeps the array under 4 GiB, which the buffer descriptor needs
   return f.num_feature <= (1u << kPackedFeatureBits) && p.num_slots < kPackedMaxSlots;
 }
 
@@ -123,6 +124,68 @@ std::vector<PackedNode> emit_packed(const Forest& f, const Placement& p, std::ve
     }
   }
   return out;
+}
+
+bool emit_super(const Forest& f, SuperForest* out) {
+  out->nodes.clear();
+  out->tree_base.clear();
+  if (f.num_feature > kSuperLeaf) return false;
+  const SuperNode unused{0.0f, 0.0f, 0.0f, kSuperLeaf | (kSuperLeaf << 5) | (kSuperLeaf << 10)};
+  struct Item {
+    int32_t node;
+    uint32_t slot;  // relative to the tree base
+  };
+  std::vector<Item> queue;
+  for (const Tree& t : f.trees) {
+    const uint32_t base = (uint32_t)out->nodes.size();
+    out->tree_base.push_back(base);
+    std::vector<SuperNode> sn(4, unused);  // group 0: the root and three unused slots
+    uint32_t next_group = 1;
+    queue.clear();
+    queue.push_back({0, 0u});
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+      const Item it = queue[qi];
+      const size_t n = (size_t)it.node;
+      SuperNode s = unused;
+      if (t.left[n] == -1) {
+        s.thr0 = t.value[n];
+      } else {
+        const size_t l = (size_t)t.left[n], r = (size_t)t.right[n];
+        const bool l_int = t.left[l] != -1, r_int = t.left[r] != -1;
+        s.thr0 = t.value[n];
+        s.thrL = t.value[l];
+        s.thrR = t.value[r];
+        uint32_t meta = (t.feature[n] & 31u) | ((l_int ? (t.feature[l] & 31u) : kSuperLeaf) << 5) |
+                        ((r_int ? (t.feature[r] & 31u) : kSuperLeaf) << 10) |
+                        ((uint32_t)(t.default_left[n] ? 1u : 0u) << 15) |
+                        ((uint32_t)(l_int && t.default_left[l] ? 1u : 0u) << 16) |
+                        ((uint32_t)(r_int && t.default_left[r] ? 1u : 0u) << 17);
+        if (l_int || r_int) {
+          const uint32_t grp = next_group++;
+          if (grp >= kSuperMaxGroups) {
+            out->nodes.clear();
+            out->tree_base.clear();
+            return false;
+          }
+          meta |= grp << 18;
+          sn.resize((size_t)next_group * 4, unused);
+          if (l_int) {
+            queue.push_back({t.left[l], grp * 4 + 0});
+            queue.push_back({t.right[l], grp * 4 + 1});
+          }
+          if (r_int) {
+            queue.push_back({t.left[r], grp * 4 + 2});
+            queue.push_back({t.right[r], grp * 4 + 3});
+          }
+        }
+        s.meta = meta;
+      }
+      sn[it.slot] = s;
+    }
+    out->nodes.insert(out->nodes.end(), sn.begin(), sn.end());
+    if (out->nodes.size() >= 0xFFFFFFF0ull) throw OhxError("booster too large for the super-node format");
+  }
+  return true;
 }
 
 std::vector<WideNode> emit_wide(const Forest& f, const Placement& p) {

@@ -60,6 +60,34 @@ constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr int kPackedFeatureBits = 5;
 constexpr uint64_t kPackedMaxSlots = 1ull << 26;
 
+// "Super-node" format (16 B, boosters with <= 31 features): one node and BOTH its children,
+// i.e. two tree levels per 16-byte gather.  On gfx950 a divergent wave64 gather costs the
+// texture addresser the same ~39 cycles whether a lane reads 4, 8 or 16 bytes
+// (tools/gather_microbench.hip), so fetching two levels at once halves the dominant cost.
+//   thr0 / thrL / thrR  split condition of the node / its left / its right child,
+//                       or the leaf value where that slot is a leaf
+//   meta  bits  0-4  feature of the node   (31 = leaf)
+//               5-9  feature of the left child  (31 = leaf)
+//              10-14 feature of the right child (31 = leaf)
+//              15,16,17 default_left of node / left / right
+//              18-31 group index, relative to the tree's base, of the four grandchild
+//                    super-nodes [LL, LR, RL, RR] stored contiguously (64 B)
+// next = tree_base + 4 * group + 2 * go_right(node) + go_right(child)
+struct SuperNode {
+  float thr0, thrL, thrR;
+  uint32_t meta;
+};
+constexpr uint32_t kSuperLeaf = 31u;
+constexpr uint32_t kSuperMaxGroups = 1u << 14;
+
+struct SuperForest {
+  std::vector<SuperNode> nodes;
+  std::vector<uint32_t> tree_base;   // index of each tree's root super-node (multiple of 4)
+};
+
+// Returns false (and leaves `out` empty) when the booster does not fit the format.
+bool emit_super(const Forest& f, SuperForest* out);
+
 Placement place_forest(const Forest& f, const LayoutParams& lp);
 bool packed_format_fits(const Forest& f, const Placement& p);
 std::vector<PackedNode> emit_packed(const Forest& f, const Placement& p, std::vector<int32_t>* orig_id);

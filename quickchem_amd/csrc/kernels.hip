@@ -31,6 +31,24 @@ constexpr int kBlock = 256;                  // 4 waves
 constexpr int kWavesPerBlock = kBlock / kWave;
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Node arrays are read through a buffer descriptor: one 64-/128-bit load per node that the
+// compiler cannot split into dword loads (it does split a plain uint2 load when only one half
+// is needed early, which doubles the gathers), a 32-bit offset instead of a 64-bit address,
+// and a hardware range check.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint2 load_node8(__amdgpu_buffer_rsrc_t r, uint32_t slot) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(slot << 3), 0, 0);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 load_node16(__amdgpu_buffer_rsrc_t r, uint32_t slot) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(slot << 4), 0, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 __device__ __forceinline__ bool is_inf(float v) { return __builtin_isinf(v); }
 
@@ -88,28 +106,41 @@ __device__ __forceinline__ uint32_t step_packed(uint2 nd, const float* __restric
   return (nd.y >> 6) - (go_left ? 1u : 0u);
 }
 
+// Packed walk, CHAINS trees at once per lane.  The loop body is straight-line code: all
+// feature reads (LDS), one wait, all compares, all node gathers - so the chains' LDS and
+// memory latencies overlap.  A chain that has reached its leaf re-reads that leaf (its
+// index no longer moves) until every lane of the wave is done with all chains; with
+// depth-capped trees that costs a few percent and keeps control flow out of the loop.
 template <int CHAINS, bool HAS_MISSING>
-__device__ __forceinline__ float walk_packed(const uint2* __restrict__ nodes, const uint32_t* __restrict__ roots,
+__device__ __forceinline__ float walk_packed(__amdgpu_buffer_rsrc_t nodes, const uint32_t* __restrict__ roots,
                                              uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile) {
   for (uint32_t t = t0; t < t1; t += CHAINS) {
     uint2 nd[CHAINS];
+    uint32_t cur[CHAINS];
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) {
       const uint32_t tt = (t + c < t1) ? t + c : t1 - 1;  // clamp: the duplicate walk is discarded
-      nd[c] = nodes[roots[tt]];
+      cur[c] = roots[tt];
+      nd[c] = load_node8(nodes, cur[c]);
     }
     bool more;
     do {
+      float x[CHAINS];
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) x[c] = tile[(nd[c].y & 31u) * kWave];
       more = false;
 #pragma unroll
       for (int c = 0; c < CHAINS; ++c) {
-        if (nd[c].y != 0u) {
-          const uint32_t n = step_packed<HAS_MISSING>(nd[c], tile);
-          nd[c] = nodes[n];
-          more = true;
-        }
+        const uint32_t m = nd[c].y;
+        bool go_left = x[c] < __uint_as_float(nd[c].x);
+        if (HAS_MISSING) go_left = go_left || ((x[c] != x[c]) && (m & 32u));
+        const uint32_t n = (m >> 6) - (go_left ? 1u : 0u);
+        cur[c] = (m != 0u) ? n : cur[c];
+        more = more || (m != 0u);
       }
-    } while (more);
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) nd[c] = load_node8(nodes, cur[c]);
+    } while (__any(more));
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c)
       if (t + c < t1) acc += __uint_as_float(nd[c].x);
@@ -133,15 +164,90 @@ __device__ __forceinline__ float walk_wide_tile(const uint4* __restrict__ nodes,
   return acc;
 }
 
-template <int CHAINS>
+// Super-node walk: one 16-byte gather brings a node and both its children, so a lane
+// descends TWO levels per gather (flatten.hpp).  Leaves are recognised by feature code 31.
+// Same phase structure as walk_packed: the chains' first-level feature reads, then their
+// second-level reads, then their gathers, with nothing but selects in between.  A chain that
+// has found its leaf parks on a leaf-only super-node image (w = all-leaf, x = value).
+template <int CHAINS, bool HAS_MISSING>
+__device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const uint32_t* __restrict__ bases,
+                                            uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile) {
+  for (uint32_t t = t0; t < t1; t += CHAINS) {
+    uint4 s[CHAINS];
+    uint32_t base[CHAINS], cur[CHAINS];
+    float leafv[CHAINS];
+    bool done[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) {
+      const uint32_t tt = (t + c < t1) ? t + c : t1 - 1;  // clamp: the duplicate walk is discarded
+      base[c] = bases[tt];
+      cur[c] = base[c];
+      s[c] = nodes[cur[c]];
+      leafv[c] = 0.0f;
+      done[c] = false;
+    }
+    bool more;
+    do {
+      float x0[CHAINS], x1[CHAINS], thr1[CHAINS];
+      bool l0[CHAINS];
+      uint32_t f1[CHAINS];
+      // level A: the node itself (feature 31 = leaf: read feature 0, result unused)
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) {
+        const uint32_t f0 = s[c].w & 31u;
+        x0[c] = tile[(f0 == 31u ? 0u : f0) * kWave];
+      }
+      // level B: the child the comparison selects
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) {
+        const uint32_t w = s[c].w;
+        bool l = x0[c] < __uint_as_float(s[c].x);
+        if (HAS_MISSING) l = l || ((x0[c] != x0[c]) && ((w >> 15) & 1u));
+        l0[c] = l;
+        thr1[c] = __uint_as_float(l ? s[c].y : s[c].z);
+        f1[c] = (w >> (l ? 5u : 10u)) & 31u;
+        x1[c] = tile[(f1[c] == 31u ? 0u : f1[c]) * kWave];
+      }
+      more = false;
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) {
+        const uint32_t w = s[c].w;
+        bool l1 = x1[c] < thr1[c];
+        if (HAS_MISSING) l1 = l1 || ((x1[c] != x1[c]) && ((w >> (l0[c] ? 16u : 17u)) & 1u));
+        const uint32_t idx = base[c] + ((w >> 18) << 2) + (l0[c] ? 0u : 2u) + (l1 ? 0u : 1u);
+        const bool leaf0 = (w & 31u) == 31u;
+        const bool leaf1 = f1[c] == 31u;
+        const bool ends = leaf0 || leaf1;
+        leafv[c] = (!done[c] && ends) ? (leaf0 ? __uint_as_float(s[c].x) : thr1[c]) : leafv[c];
+        done[c] = done[c] || ends;
+        cur[c] = done[c] ? cur[c] : idx;   // a finished chain keeps re-reading where it stopped
+        more = more || !done[c];
+      }
+      // the gathers, unconditional: straight-line code, nothing to wait for between them
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) s[c] = nodes[cur[c]];
+    } while (__any(more));
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+      if (t + c < t1) acc += leafv[c];
+  }
+  return acc;
+}
+
+// FMT: 0 = wide 16-byte nodes, 1 = packed 8-byte nodes, 2 = 16-byte super-nodes
+template <int FMT, int CHAINS>
 __device__ __forceinline__ float walk_tile(const DeviceForest& fr, uint32_t t0, uint32_t t1, const float* tile,
                                            bool wave_has_missing) {
   float acc = fr.base_score;
-  if constexpr (CHAINS > 0) {
-    const uint2* nodes = reinterpret_cast<const uint2*>(fr.packed);
-    constexpr int C = CHAINS;
-    return wave_has_missing ? walk_packed<C, true>(nodes, fr.roots, t0, t1, acc, tile)
-                            : walk_packed<C, false>(nodes, fr.roots, t0, t1, acc, tile);
+  if constexpr (FMT == 1) {
+    const __amdgpu_buffer_rsrc_t nodes = make_rsrc(fr.packed, fr.packed_bytes);
+    return wave_has_missing ? walk_packed<CHAINS, true>(nodes, fr.roots, t0, t1, acc, tile)
+                            : walk_packed<CHAINS, false>(nodes, fr.roots, t0, t1, acc, tile);
+  } else if constexpr (FMT == 2) {
+    // plain 128-bit global loads: measured 8 % faster than buffer loads on the divergent deep levels
+    const uint4* nodes = reinterpret_cast<const uint4*>(fr.super);
+    return wave_has_missing ? walk_super<CHAINS, true>(nodes, fr.super_base, t0, t1, acc, tile)
+                            : walk_super<CHAINS, false>(nodes, fr.super_base, t0, t1, acc, tile);
   } else {
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
     return wave_has_missing ? walk_wide_tile<true>(nodes, fr.roots, t0, t1, acc, tile)
@@ -151,25 +257,29 @@ __device__ __forceinline__ float walk_tile(const DeviceForest& fr, uint32_t t0, 
 
 // ------------------------------------------------------------------ kernels
 
-// AoS rows in, margins out.  CHAINS = 0 selects the 16-byte node format.
-template <int CHAINS>
+// AoS rows in, margins out.
+template <int FMT, int CHAINS>
 __global__ __launch_bounds__(kBlock) void predict_rows_tile_kernel(DeviceForest fr, PredictArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   float* tile = lds + (size_t)wave * fr.num_feature * kWave + lane;
   const bool missing_is_nan = a.missing != a.missing;
-  const uint64_t ntiles = (a.nrow + kWave - 1) / kWave;
-  const uint64_t wave_id = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  // Blocks b and b + 8 share an XCD (round-robin dispatch, observed, speed only): give
+  // every XCD one contiguous run of tiles so that its CUs walk neighbouring gridcells and
+  // share node lines in that XCD's L2.
+  uint32_t block = blockIdx.x;
+  if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint64_t wave_id = (uint64_t)block * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
-  for (uint64_t tile_id = wave_id; tile_id < ntiles; tile_id += nwaves) {
+  for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
     const uint64_t row = tile_id * kWave + lane;
     const bool valid = row < a.nrow;
     const bool lane_nan = fill_tile_rows(tile, a.rows, row, valid, a.ncol, fr.num_feature, a.missing,
                                          missing_is_nan, a.flags);
     const bool wave_nan = __any(lane_nan);
     // the tile is private to this wave: its own LDS writes are ordered before its reads
-    const float acc = walk_tile<CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
+    const float acc = walk_tile<FMT, CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
     if (valid) __builtin_nontemporal_store(acc, a.out + row);
   }
 }
@@ -212,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void predict_rows_direct_kernel(DeviceFores
 // The fused path: reads the MAPL fields in place (lane = consecutive i, coalesced),
 // applies PL/100 (OH_GridCompMod.F90:314), walks, writes 10**pred * OHscale
 // (OH_GridCompMod.F90:369,1569) into OH_ML(i,j,k1..k2).
-template <int CHAINS>
+template <int FMT, int CHAINS>
 __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr, FieldsArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -247,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
     }
     if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
     const bool wave_nan = __any(lane_nan);
-    const float acc = walk_tile<CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
+    const float acc = walk_tile<FMT, CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
     if (valid) {
       if (a.margin_out) a.margin_out[m] = acc;
       float oh = acc;
@@ -348,6 +458,33 @@ hipError_t ensure_lds(K kernel, size_t lds_bytes) {
   return hipSuccess;
 }
 
+// One launch, or a train of launches of one residency (grid x 4 tiles) each.
+template <class K>
+hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, PredictArgs a, int num_cus,
+                             hipStream_t stream, const LaunchTuning& tune) {
+  hipError_t e = ensure_lds(kernel, lds);
+  if (e != hipSuccess) return e;
+  const int grid = tile_grid(kernel, lds, a.nrow, num_cus);
+  const uint64_t ntiles = (a.nrow + kWave - 1) / kWave;
+  a.xcd_remap = tune.xcd_remap;
+  if (tune.launches_per_residency <= 0) {
+    a.tile_begin = 0;
+    a.tile_end = ntiles;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+    return hipGetLastError();
+  }
+  const uint64_t per_launch = (uint64_t)grid * kWavesPerBlock * (uint64_t)tune.launches_per_residency;
+  for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
+    a.tile_begin = t0;
+    a.tile_end = t0 + per_launch < ntiles ? t0 + per_launch : ntiles;
+    const uint64_t blocks = (a.tile_end - a.tile_begin + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < (uint64_t)grid ? blocks : (uint64_t)grid)), dim3(kBlock), lds,
+                       stream, fr, a);
+  }
+  return hipGetLastError();
+}
+
+
 }  // namespace
 
 const char* kernel_kind_name(KernelKind k) {
@@ -356,44 +493,35 @@ const char* kernel_kind_name(KernelKind k) {
     case KernelKind::Packed1: return "packed1";
     case KernelKind::Packed2: return "packed2";
     case KernelKind::Packed4: return "packed4";
+    case KernelKind::Super1: return "super1";
+    case KernelKind::Super2: return "super2";
+    case KernelKind::Super4: return "super4";
   }
   return "?";
 }
 
 hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const PredictArgs& a, int num_cus,
-                          hipStream_t stream) {
+                          hipStream_t stream, const LaunchTuning& tune) {
   if (a.nrow == 0) return hipSuccess;
   const size_t lds = (size_t)kWavesPerBlock * fr.num_feature * kWave * sizeof(float);
   const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && a.ncol <= fr.num_feature;
-  if (a.pred_leaf || kind == KernelKind::Wide || !tile_ok || fr.packed == nullptr) {
+  const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super4;
+  if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
+  if (a.pred_leaf || kind == KernelKind::Wide || !tile_ok || (!is_super && fr.packed == nullptr)) {
     if (fr.wide == nullptr) return hipErrorInvalidValue;
     const int grid = grid_for(a.nrow, num_cus, 8);
     if (a.pred_leaf) hipLaunchKernelGGL(predict_rows_direct_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, fr, a);
     else hipLaunchKernelGGL(predict_rows_direct_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, fr, a);
     return hipGetLastError();
   }
-  hipError_t e = hipSuccess;
   switch (kind) {
-    case KernelKind::Packed1: {
-      if ((e = ensure_lds(predict_rows_tile_kernel<1>, lds)) != hipSuccess) return e;
-      const int grid = tile_grid(predict_rows_tile_kernel<1>, lds, a.nrow, num_cus);
-      hipLaunchKernelGGL(predict_rows_tile_kernel<1>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
-      break;
-    }
-    case KernelKind::Packed2: {
-      if ((e = ensure_lds(predict_rows_tile_kernel<2>, lds)) != hipSuccess) return e;
-      const int grid = tile_grid(predict_rows_tile_kernel<2>, lds, a.nrow, num_cus);
-      hipLaunchKernelGGL(predict_rows_tile_kernel<2>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
-      break;
-    }
-    default: {
-      if ((e = ensure_lds(predict_rows_tile_kernel<4>, lds)) != hipSuccess) return e;
-      const int grid = tile_grid(predict_rows_tile_kernel<4>, lds, a.nrow, num_cus);
-      hipLaunchKernelGGL(predict_rows_tile_kernel<4>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
-      break;
-    }
+    case KernelKind::Packed1: return launch_rows_tiled(predict_rows_tile_kernel<1, 1>, lds, fr, a, num_cus, stream, tune);
+    case KernelKind::Packed2: return launch_rows_tiled(predict_rows_tile_kernel<1, 2>, lds, fr, a, num_cus, stream, tune);
+    case KernelKind::Packed4: return launch_rows_tiled(predict_rows_tile_kernel<1, 4>, lds, fr, a, num_cus, stream, tune);
+    case KernelKind::Super1: return launch_rows_tiled(predict_rows_tile_kernel<2, 1>, lds, fr, a, num_cus, stream, tune);
+    case KernelKind::Super4: return launch_rows_tiled(predict_rows_tile_kernel<2, 4>, lds, fr, a, num_cus, stream, tune);
+    default: return launch_rows_tiled(predict_rows_tile_kernel<2, 2>, lds, fr, a, num_cus, stream, tune);
   }
-  return hipGetLastError();
 }
 
 hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const FieldsArgs& a, int num_cus,
@@ -402,27 +530,28 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   const uint64_t nrow = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)(a.k2 - a.k1 + 1);
   const size_t lds = (size_t)kWavesPerBlock * fr.num_feature * kWave * sizeof(float);
   if (fr.num_feature < 1 || lds > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t e = hipSuccess;
-  const bool use_wide = (kind == KernelKind::Wide || fr.packed == nullptr);
-  if (use_wide) {
-    if (fr.wide == nullptr) return hipErrorInvalidValue;
-    if ((e = ensure_lds(predict_fields_kernel<0>, lds)) != hipSuccess) return e;
-    const int grid = tile_grid(predict_fields_kernel<0>, lds, nrow, num_cus);
-    hipLaunchKernelGGL(predict_fields_kernel<0>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
-  } else if (kind == KernelKind::Packed1) {
-    if ((e = ensure_lds(predict_fields_kernel<1>, lds)) != hipSuccess) return e;
-    const int grid = tile_grid(predict_fields_kernel<1>, lds, nrow, num_cus);
-    hipLaunchKernelGGL(predict_fields_kernel<1>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
-  } else if (kind == KernelKind::Packed2) {
-    if ((e = ensure_lds(predict_fields_kernel<2>, lds)) != hipSuccess) return e;
-    const int grid = tile_grid(predict_fields_kernel<2>, lds, nrow, num_cus);
-    hipLaunchKernelGGL(predict_fields_kernel<2>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
-  } else {
-    if ((e = ensure_lds(predict_fields_kernel<4>, lds)) != hipSuccess) return e;
-    const int grid = tile_grid(predict_fields_kernel<4>, lds, nrow, num_cus);
-    hipLaunchKernelGGL(predict_fields_kernel<4>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+  const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super4;
+  if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
+  const bool use_wide = kind == KernelKind::Wide || (!is_super && fr.packed == nullptr);
+  if (use_wide && fr.wide == nullptr) return hipErrorInvalidValue;
+#define OHX_LAUNCH_FIELDS(FMT, CH)                                                                       \
+  do {                                                                                                   \
+    hipError_t e = ensure_lds(predict_fields_kernel<FMT, CH>, lds);                                      \
+    if (e != hipSuccess) return e;                                                                       \
+    const int grid = tile_grid(predict_fields_kernel<FMT, CH>, lds, nrow, num_cus);                      \
+    hipLaunchKernelGGL((predict_fields_kernel<FMT, CH>), dim3(grid), dim3(kBlock), lds, stream, fr, a);  \
+    return hipGetLastError();                                                                            \
+  } while (0)
+  if (use_wide) OHX_LAUNCH_FIELDS(0, 1);
+  switch (kind) {
+    case KernelKind::Packed1: OHX_LAUNCH_FIELDS(1, 1);
+    case KernelKind::Packed2: OHX_LAUNCH_FIELDS(1, 2);
+    case KernelKind::Packed4: OHX_LAUNCH_FIELDS(1, 4);
+    case KernelKind::Super1: OHX_LAUNCH_FIELDS(2, 1);
+    case KernelKind::Super4: OHX_LAUNCH_FIELDS(2, 4);
+    default: OHX_LAUNCH_FIELDS(2, 2);
   }
-  return hipGetLastError();
+#undef OHX_LAUNCH_FIELDS
 }
 
 hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream) {

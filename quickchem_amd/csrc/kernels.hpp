@@ -18,9 +18,15 @@ struct DeviceForest {
   const WideNode* wide = nullptr;       // may be null until first needed
   const uint32_t* roots = nullptr;
   const int32_t* packed_orig_id = nullptr;
+  const SuperNode* super = nullptr;     // may be null (booster does not qualify)
+  const uint32_t* super_base = nullptr; // per tree
   uint32_t num_trees = 0;
   uint32_t num_feature = 0;
   float base_score = 0.0f;
+  // sizes in bytes of the packed / super arrays (< 4 GiB: they are read through buffer
+  // descriptors, whose range check also turns any stray index into a harmless zero read)
+  uint32_t packed_bytes = 0;
+  uint32_t super_bytes = 0;
 };
 
 struct PredictArgs {
@@ -32,6 +38,17 @@ struct PredictArgs {
   float* out = nullptr;         // [nrow] margins, or [nrow][ntree] leaf ids when pred_leaf
   bool pred_leaf = false;
   uint32_t* flags = nullptr;    // device word, OR-ed with kFlag*
+  uint64_t tile_begin = 0;      // first 64-row tile of this launch (tile kernels)
+  uint64_t tile_end = 0;        // one past the last tile of this launch
+  int xcd_remap = 1;            // give each XCD a contiguous range of tiles
+};
+
+struct LaunchTuning {
+  // 0: one launch for the whole batch (waves stride over tiles).  > 0: one launch per this many
+  // "waves of tiles": every launch starts all resident waves on tree 0 together, so the waves of
+  // an XCD walk the same few trees at the same time and share their node lines in that XCD's L2.
+  int launches_per_residency = 1;
+  int xcd_remap = 1;
 };
 
 // 27 SoA fields of the MAPL state (OH_GridCompMod.F90:313-339), device pointers.
@@ -52,12 +69,12 @@ struct FieldsArgs {
   uint32_t* flags = nullptr;
 };
 
-enum class KernelKind { Wide, Packed1, Packed2, Packed4 };
+enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super4 };
 
 const char* kernel_kind_name(KernelKind k);
 
 hipError_t launch_predict(KernelKind kind, const DeviceForest& forest, const PredictArgs& a, int num_cus,
-                          hipStream_t stream);
+                          hipStream_t stream, const LaunchTuning& tune = LaunchTuning());
 hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& forest, const FieldsArgs& a, int num_cus,
                                  hipStream_t stream);
 hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream);

@@ -39,19 +39,20 @@ def test_full_size_properties(full_model, gridname, shard):
     synth.rows_device(grid, row0, n, rows)
     synth.inject_missing_device(rows, 100)                     # 1e-4 of the entries: -999.0 or NaN
     booster = capi.Booster(model_buffer=full_model.image)
-    a = _predict_dev(torch, booster, rows, "packed4")
+    a = _predict_dev(torch, booster, rows, "auto")             # the shipped default (super-nodes, 2 chains)
     b = _predict_dev(torch, booster, rows, "wide")             # different node format, no LDS tile, 1 chain
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
-    c = _predict_dev(torch, booster, rows, "packed1")
-    assert torch.equal(a.view(torch.int32), c.view(torch.int32))
+    for other in ("packed1", "packed4", "super1", "super4"):
+        c = _predict_dev(torch, booster, rows, other)
+        assert torch.equal(a.view(torch.int32), c.view(torch.int32)), other
     # shards concatenate to the whole (what the 8-GPU run relies on)
     cut = (n // 3) // 64 * 64 + 17
-    parts = [_predict_dev(torch, booster, rows[:cut], "packed4"), _predict_dev(torch, booster, rows[cut:], "packed4")]
+    parts = [_predict_dev(torch, booster, rows[:cut], "auto"), _predict_dev(torch, booster, rows[cut:], "auto")]
     assert torch.equal(torch.cat(parts).view(torch.int32), a.view(torch.int32))
     # permutation equivariance on a block
     perm = torch.randperm(100_000, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     sub = rows[:100_000][perm].contiguous()
-    assert torch.equal(_predict_dev(torch, booster, sub, "packed4").view(torch.int32), a[:100_000][perm].view(torch.int32))
+    assert torch.equal(_predict_dev(torch, booster, sub, "auto").view(torch.int32), a[:100_000][perm].view(torch.int32))
     # a random sample against the oracle, on the very same bytes
     idx = torch.randint(0, n, (50_000,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
     sample = rows[idx].cpu().numpy()

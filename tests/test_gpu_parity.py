@@ -14,7 +14,7 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["wide", "packed1", "packed2", "packed4"]
+KERNELS = ["wide", "packed1", "packed2", "packed4", "super1", "super2", "super4"]
 
 
 @pytest.fixture(scope="module")
@@ -91,7 +91,7 @@ def test_missing_values_vs_oracle(torch_cuda, deep_model, kernel, missing):
     assert np.array_equal(helpers.bits(got), helpers.bits(want))
 
 
-@pytest.mark.parametrize("kernel", ["wide", "packed4"])
+@pytest.mark.parametrize("kernel", ["wide", "packed4", "super2"])
 def test_ntree_limit_and_leaf_indices(torch_cuda, small_model, kernel):
     rows = with_missing(synth.rows_cpu(synth.GRIDS["C12"], 0, 3000), 0.005)
     for lim in (1, 7, 19, 20, 500):
@@ -110,12 +110,15 @@ def test_layout_does_not_change_results(torch_cuda, deep_model, params):
     want = helpers.oracle_predict(deep_model.image, rows, synth.XX_MISS)
     got = gpu_predict(deep_model.image, rows, synth.XX_MISS, "packed4", params=params)
     assert np.array_equal(helpers.bits(got), helpers.bits(want))
+    got = gpu_predict(deep_model.image, rows, synth.XX_MISS, "super2",
+                      params={"ohx_launches_per_residency": 0, "ohx_xcd_remap": 0})
+    assert np.array_equal(helpers.bits(got), helpers.bits(want))
 
 
 def test_fewer_columns_than_features(torch_cuda, small_model):
     rows = synth.rows_cpu(synth.GRIDS["C12"], 0, 4096)[:, :20].copy()
     want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
-    for kernel in ("wide", "packed4"):
+    for kernel in ("wide", "packed4", "super2"):
         got = gpu_predict(small_model.image, rows, synth.XX_MISS, kernel)
         assert np.array_equal(helpers.bits(got), helpers.bits(want))
 

@@ -64,7 +64,10 @@ def test_file_round_trip_through_the_abi(tmp_path, small_model):
     assert p_bin2.read_bytes() == small_model.image.tobytes()
     info = b2.info()
     assert info["num_trees"] == small_model.num_trees and info["num_nodes"] == small_model.num_nodes
-    assert info["num_slots"] >= info["num_nodes"] and info["packed"] == 1 and info["num_feature"] == 27
+    assert info["num_slots"] >= info["num_nodes"] // 2 and info["packed"] == 2 and info["num_feature"] == 27
+    b2.set_param("ohx_kernel", "packed2")
+    info = b2.info()
+    assert info["num_slots"] >= info["num_nodes"] and info["packed"] == 1
 
 
 @pytest.mark.parametrize("mutation", ["truncate", "bad_child", "ubj", "garbage_json", "nonadjacent"])
@@ -103,6 +106,9 @@ def test_missing_file_and_unloaded_booster(tmp_path):
 
 def test_layout_parameters_change_slots_not_nodes(deep_model):
     b = capi.Booster(model_buffer=deep_model.image)
+    sup = b.info()
+    assert sup["packed"] == 2 and sup["node_bytes"] == 16 * sup["num_slots"] and sup["num_slots"] % 4 == 0
+    b.set_param("ohx_kernel", "packed2")
     base = b.info()
     b.set_param("ohx_line_slots", 0)
     bfs = b.info()
