@@ -153,7 +153,7 @@ struct BoosterObj {
   DevBuf<PackedNode> d_packed;
   DevBuf<WideNode> d_wide;
   DevBuf<SuperNode> d_super;
-  DevBuf<uint32_t> d_super_base;
+  DevBuf<SuperTreeHead> d_super_heads;
   bool super_ok = false;
   uint64_t super_slots = 0;
   DevBuf<uint32_t> d_roots;
@@ -197,7 +197,7 @@ void invalidate_device_state(BoosterObj& b) {
   b.d_packed.release();
   b.d_wide.release();
   b.d_super.release();
-  b.d_super_base.release();
+  b.d_super_heads.release();
   b.super_ok = false;
   b.d_roots.release();
 }
@@ -224,7 +224,7 @@ void ensure_uploaded(BoosterObj& b) {
     if (b.super_ok) {
       b.super_slots = sf.nodes.size();
       b.d_super.upload(sf.nodes);
-      b.d_super_base.upload(sf.tree_base);
+      b.d_super_heads.upload(sf.heads);
     }
   }
   if (b.packed_ok && !(b.super_ok && wants_super(b.kernel_name))) {
@@ -243,7 +243,7 @@ DeviceForest device_forest(const BoosterObj& b) {
   d.wide = b.d_wide.p;
   d.roots = b.d_roots.p;
   d.super = b.d_super.p;
-  d.super_base = b.d_super_base.p;
+  d.super_heads = b.d_super_heads.p;
   d.packed_bytes = (uint32_t)(b.d_packed.n * sizeof(PackedNode));
   d.super_bytes = (uint32_t)(b.d_super.n * sizeof(SuperNode));
   d.num_trees = (uint32_t)b.forest.trees.size();

@@ -1,6 +1,7 @@
 #include "flatten.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <deque>
 
@@ -126,9 +127,38 @@ std::vector<PackedNode> emit_packed(const Forest& f, const Placement& p, std::ve
   return out;
 }
 
+namespace {
+
+// Which levels start a super-node.  A leaf that sits in a child slot of its parent's
+// super-node costs nothing; a leaf that would START a super-node costs one more gather, and
+// that gather is the most divergent one of the walk.  With phase 1 the root is hung under a
+// virtual always-left node, so super-nodes start at odd levels and leaves at EVEN depth (the
+// depth cap of an 18-level model) ride in child slots; the odd gather moves to the top of the
+// tree, where all lanes read the same 16 bytes.  Choose per tree by training cover.
+int choose_super_phase(const Tree& t) {
+  double cost[2] = {0.0, 0.0};
+  bool have_cover = false;
+  for (float h : t.sum_hess) have_cover = have_cover || h > 0.0f;
+  std::vector<std::pair<int32_t, int>> stack{{0, 0}};
+  while (!stack.empty()) {
+    auto [n, d] = stack.back();
+    stack.pop_back();
+    if (t.left[(size_t)n] == -1) {
+      const double w = have_cover ? (double)t.sum_hess[(size_t)n] : 1.0;
+      cost[d & 1] += w;  // phase p (super-nodes start at levels of parity p) pays for leaves of depth parity p
+    } else {
+      stack.emplace_back(t.left[(size_t)n], d + 1);
+      stack.emplace_back(t.right[(size_t)n], d + 1);
+    }
+  }
+  return cost[1] < cost[0] ? 1 : 0;   // fewer paid leaves wins; ties keep phase 0
+}
+
+}  // namespace
+
 bool emit_super(const Forest& f, SuperForest* out) {
   out->nodes.clear();
-  out->tree_base.clear();
+  out->heads.clear();
   if (f.num_feature > kSuperLeaf) return false;
   const SuperNode unused{0.0f, 0.0f, 0.0f, kSuperLeaf | (kSuperLeaf << 5) | (kSuperLeaf << 10)};
   struct Item {
@@ -138,11 +168,24 @@ bool emit_super(const Forest& f, SuperForest* out) {
   std::vector<Item> queue;
   for (const Tree& t : f.trees) {
     const uint32_t base = (uint32_t)out->nodes.size();
-    out->tree_base.push_back(base);
-    std::vector<SuperNode> sn(4, unused);  // group 0: the root and three unused slots
+    SuperTreeHead head{base, 0u, 0.0f, 0u};
+    std::vector<SuperNode> sn(4, unused);  // group 0: the root (phase 0) and three unused slots
     uint32_t next_group = 1;
     queue.clear();
-    queue.push_back({0, 0u});
+    const bool root_is_leaf = t.left[0] == -1;
+    const int phase = root_is_leaf ? 0 : choose_super_phase(t);
+    if (phase == 1) {
+      // the root is evaluated from the head record; its children start the super-nodes
+      head.root_meta = (t.feature[0] & 31u) | ((uint32_t)(t.default_left[0] ? 1u : 0u) << 5) | (1u << 8);
+      head.root_thr = t.value[0];
+      const uint32_t grp = next_group++;
+      sn.resize((size_t)next_group * 4, unused);
+      queue.push_back({t.left[0], grp * 4 + 0});
+      queue.push_back({t.right[0], grp * 4 + 1});
+    } else {
+      queue.push_back({0, 0u});
+    }
+    out->heads.push_back(head);
     for (size_t qi = 0; qi < queue.size(); ++qi) {
       const Item it = queue[qi];
       const size_t n = (size_t)it.node;
@@ -164,7 +207,7 @@ bool emit_super(const Forest& f, SuperForest* out) {
           const uint32_t grp = next_group++;
           if (grp >= kSuperMaxGroups) {
             out->nodes.clear();
-            out->tree_base.clear();
+            out->heads.clear();
             return false;
           }
           meta |= grp << 18;

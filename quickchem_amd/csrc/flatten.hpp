@@ -80,9 +80,19 @@ struct SuperNode {
 constexpr uint32_t kSuperLeaf = 31u;
 constexpr uint32_t kSuperMaxGroups = 1u << 14;
 
+// Per tree: where the walk starts.  Phase-0 trees start at super-node `base`.  Phase-1 trees
+// (super-nodes start at odd levels) evaluate the root from this record - it is the same for
+// every lane, so it comes through scalar loads - and start at base + 4 + go_right(root).
+struct SuperTreeHead {
+  uint32_t base;        // index of the tree's first super-node (multiple of 4)
+  uint32_t root_meta;   // bit 8: phase; bits 0-4: root feature; bit 5: root default_left
+  float root_thr;
+  uint32_t pad;
+};
+
 struct SuperForest {
   std::vector<SuperNode> nodes;
-  std::vector<uint32_t> tree_base;   // index of each tree's root super-node (multiple of 4)
+  std::vector<SuperTreeHead> heads;
 };
 
 // Returns false (and leaves `out` empty) when the booster does not fit the format.

@@ -170,22 +170,40 @@ __device__ __forceinline__ float walk_wide_tile(const uint4* __restrict__ nodes,
 // second-level reads, then their gathers, with nothing but selects in between.  A chain that
 // has found its leaf parks on a leaf-only super-node image (w = all-leaf, x = value).
 template <int CHAINS, bool HAS_MISSING>
-__device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const uint32_t* __restrict__ bases,
+__device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const SuperTreeHead* __restrict__ heads,
                                             uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile) {
+  if (t0 >= t1) return acc;
+  // tree heads are wave-uniform (scalar loads); the next group's are fetched a whole walk ahead
+  SuperTreeHead hn[CHAINS];
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) hn[c] = heads[(t0 + c < t1) ? t0 + c : t1 - 1];
   for (uint32_t t = t0; t < t1; t += CHAINS) {
-    uint4 s[CHAINS];
-    uint32_t base[CHAINS], cur[CHAINS];
-    float leafv[CHAINS];
-    bool done[CHAINS];
+    SuperTreeHead h[CHAINS];
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) {
-      const uint32_t tt = (t + c < t1) ? t + c : t1 - 1;  // clamp: the duplicate walk is discarded
-      base[c] = bases[tt];
-      cur[c] = base[c];
-      s[c] = nodes[cur[c]];
+      h[c] = hn[c];
+      const uint32_t tn = t + CHAINS + c;
+      hn[c] = heads[tn < t1 ? tn : t1 - 1];               // clamp: a duplicate walk is discarded below
+    }
+    uint4 s[CHAINS];
+    uint32_t base[CHAINS], cur[CHAINS];
+    float leafv[CHAINS], xr[CHAINS];
+    bool done[CHAINS];
+    // phase-1 trees evaluate their root here, from the head record (same for every lane);
+    // straight-line: all reads, all selects, all gathers
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) xr[c] = tile[(h[c].root_meta & 31u) * kWave];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) {
+      bool l = xr[c] < h[c].root_thr;
+      if (HAS_MISSING) l = l || ((xr[c] != xr[c]) && (h[c].root_meta & 32u));
+      base[c] = h[c].base;
+      cur[c] = (h[c].root_meta & 0x100u) ? h[c].base + 4u + (l ? 0u : 1u) : h[c].base;
       leafv[c] = 0.0f;
       done[c] = false;
     }
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) s[c] = nodes[cur[c]];
     bool more;
     do {
       float x0[CHAINS], x1[CHAINS], thr1[CHAINS];
@@ -246,8 +264,8 @@ __device__ __forceinline__ float walk_tile(const DeviceForest& fr, uint32_t t0, 
   } else if constexpr (FMT == 2) {
     // plain 128-bit global loads: measured 8 % faster than buffer loads on the divergent deep levels
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.super);
-    return wave_has_missing ? walk_super<CHAINS, true>(nodes, fr.super_base, t0, t1, acc, tile)
-                            : walk_super<CHAINS, false>(nodes, fr.super_base, t0, t1, acc, tile);
+    return wave_has_missing ? walk_super<CHAINS, true>(nodes, fr.super_heads, t0, t1, acc, tile)
+                            : walk_super<CHAINS, false>(nodes, fr.super_heads, t0, t1, acc, tile);
   } else {
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
     return wave_has_missing ? walk_wide_tile<true>(nodes, fr.roots, t0, t1, acc, tile)

@@ -19,7 +19,7 @@ struct DeviceForest {
   const uint32_t* roots = nullptr;
   const int32_t* packed_orig_id = nullptr;
   const SuperNode* super = nullptr;     // may be null (booster does not qualify)
-  const uint32_t* super_base = nullptr; // per tree
+  const SuperTreeHead* super_heads = nullptr; // per tree
   uint32_t num_trees = 0;
   uint32_t num_feature = 0;
   float base_score = 0.0f;
