@@ -160,7 +160,7 @@ bool emit_super(const Forest& f, SuperForest* out) {
   out->nodes.clear();
   out->heads.clear();
   if (f.num_feature > kSuperLeaf) return false;
-  const SuperNode unused{0.0f, 0.0f, 0.0f, kSuperLeaf | (kSuperLeaf << 5) | (kSuperLeaf << 10)};
+  const SuperNode unused{0.0f, 0.0f, 0.0f, super_meta(kSuperLeaf, kSuperLeaf, kSuperLeaf, 0, 0, 0, 0)};
   struct Item {
     int32_t node;
     uint32_t slot;  // relative to the tree base
@@ -198,11 +198,9 @@ bool emit_super(const Forest& f, SuperForest* out) {
         s.thr0 = t.value[n];
         s.thrL = t.value[l];
         s.thrR = t.value[r];
-        uint32_t meta = (t.feature[n] & 31u) | ((l_int ? (t.feature[l] & 31u) : kSuperLeaf) << 5) |
-                        ((r_int ? (t.feature[r] & 31u) : kSuperLeaf) << 10) |
-                        ((uint32_t)(t.default_left[n] ? 1u : 0u) << 15) |
-                        ((uint32_t)(l_int && t.default_left[l] ? 1u : 0u) << 16) |
-                        ((uint32_t)(r_int && t.default_left[r] ? 1u : 0u) << 17);
+        uint32_t meta = super_meta(t.feature[n], l_int ? t.feature[l] : kSuperLeaf, r_int ? t.feature[r] : kSuperLeaf,
+                                   t.default_left[n] ? 1u : 0u, (l_int && t.default_left[l]) ? 1u : 0u,
+                                   (r_int && t.default_left[r]) ? 1u : 0u, 0u);
         if (l_int || r_int) {
           const uint32_t grp = next_group++;
           if (grp >= kSuperMaxGroups) {

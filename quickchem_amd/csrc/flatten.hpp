@@ -66,10 +66,11 @@ constexpr uint64_t kPackedMaxSlots = 1ull << 26;
 // (tools/gather_microbench.hip), so fetching two levels at once halves the dominant cost.
 //   thr0 / thrL / thrR  split condition of the node / its left / its right child,
 //                       or the leaf value where that slot is a leaf
-//   meta  bits  0-4  feature of the node   (31 = leaf)
-//               5-9  feature of the left child  (31 = leaf)
-//              10-14 feature of the right child (31 = leaf)
-//              15,16,17 default_left of node / left / right
+//   meta  bits  0-4  feature of the left child  (31 = leaf)
+//               5,6,7 default_left of node / left child / right child
+//               8-12 feature of the node (31 = leaf); at bit 8 so that `meta & 0x1F00` IS the
+//                    byte offset of that feature's row in the LDS tile (64 lanes x 4 B)
+//              13-17 feature of the right child (31 = leaf)
 //              18-31 group index, relative to the tree's base, of the four grandchild
 //                    super-nodes [LL, LR, RL, RR] stored contiguously (64 B)
 // next = tree_base + 4 * group + 2 * go_right(node) + go_right(child)
@@ -78,6 +79,10 @@ struct SuperNode {
   uint32_t meta;
 };
 constexpr uint32_t kSuperLeaf = 31u;
+constexpr uint32_t super_meta(uint32_t f0, uint32_t fl, uint32_t fr, uint32_t dl0, uint32_t dll, uint32_t dlr,
+                              uint32_t group) {
+  return (fl & 31u) | (dl0 << 5) | (dll << 6) | (dlr << 7) | ((f0 & 31u) << 8) | ((fr & 31u) << 13) | (group << 18);
+}
 constexpr uint32_t kSuperMaxGroups = 1u << 14;
 
 // Per tree: where the walk starts.  Phase-0 trees start at super-node `base`.  Phase-1 trees
