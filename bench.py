@@ -69,15 +69,36 @@ def cpu_baseline(model_image, rows_dev, budget_s):
         d.free()
         return time.perf_counter() - t0, out
 
-    probe = min(65536, rows_dev.shape[0])
+    probe = min(524288, rows_dev.shape[0])
+    run(min(4096, probe))                       # thread pool and page faults out of the way
     t_probe, _ = run(probe)
     rate = probe / max(t_probe, 1e-6)
-    n = int(min(rows_dev.shape[0], max(probe, rate * budget_s)))
+    n = int(min(rows_dev.shape[0], max(probe, 0.7 * rate * budget_s)))
     n = max(64, n // 64 * 64)
     t, out = run(n)
     return {"value": n / t, "unit": "gridcells/s", "cores": cores, "kind": "port",
             "sample": f"first {n} rows of the batch, oracle/xgb_oracle.c (OpenMP, {cores} threads), "
                       f"XGDMatrixCreateFromMat + XGBoosterPredict, {t:.2f} s"}, out, n
+
+
+def measured_traffic(grid_name, kernel, model_nodes):
+    """HBM-side bytes per step from the committed rocprofv3 --pmc passes (profiles/), if they
+    were taken on this very workload; None otherwise (PMC cannot be collected from in here)."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(pdir):
+        return None
+    for name in sorted(os.listdir(pdir)):
+        if not name.endswith("_traffic.json"):
+            continue
+        try:
+            t = json.load(open(os.path.join(pdir, name)))
+        except Exception:
+            continue
+        if t.get("workload") == grid_name and t.get("model_nodes") == model_nodes and \
+                kernel in ("auto", t.get("kernel")):
+            best = t.get("traffic_bytes_per_step")
+    return best
 
 
 def main():
@@ -171,6 +192,8 @@ def main():
         kernel_s = float(t.item())
 
     info = booster.info()
+    tiles = (n_local + 63) // 64
+    launches_per_step = -(-tiles // (256 * 20))     # one launch per residency of 256 CUs x 20 waves
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total / (elapsed / args.steps)
     algo_bytes = BYTES_PER_CELL * n_local + info["node_bytes"]
@@ -207,9 +230,14 @@ def main():
                 "parallelism": f"rows{world}",
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "predict_rows_tile_kernel", "kernel_ms": kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.grid, args.kernel, info["num_nodes"])
+                         if (world == 1 and not args.shuffle and not args.missing_ppm and not args.param) else None,
+                         "kernel": "predict_rows_tile_kernel<2,2>", "kernel_ms": kernel_s * 1e3,
+                         "per": "step = the train of launches of one pass over the batch",
+                         "launches_per_step": launches_per_step,
+                         "avg_launch_us": kernel_s * 1e6 / launches_per_step,
+                         "algorithmic_bytes": algo_bytes},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
