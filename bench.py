@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--missing-ppm", type=int, default=0, help="inject -999.0/NaN at this rate per million entries")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--shuffle", action="store_true", help="permute the rows (destroys spatial coherence)")
+    ap.add_argument("--path", default="rows", choices=["rows", "fields"],
+                    help="rows: AoS xx_carr -> margins (the headline); fields: the fused SoA call, 27 MAPL fields -> "
+                         "10**pred*OHscale (1 GPU only)")
     return ap.parse_args()
 
 
@@ -101,6 +104,51 @@ def measured_traffic(grid_name, kernel, model_nodes):
     return best
 
 
+def bench_fields(args, grid, n_total, model, booster, dev, t_model):
+    """The fused SoA variant (23 3-D reads + 4 2-D reads + 1 write per gridcell)."""
+    from quickchem_amd import synth
+    im, jm, km = grid
+    plane = im * jm
+    fields = []
+    for f in range(synth.NFEAT):
+        t = torch.empty(plane * (1 if synth.IS2D[f] else km), dtype=torch.float32, device=dev)
+        synth.field_device(grid, f, t)
+        fields.append(t)
+    oh = torch.zeros(plane * km, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+    ptrs = [t.data_ptr() for t in fields]
+
+    def step():
+        booster.predict_fields_device(ptrs, synth.IS2D, synth.PL_FEATURE, im, jm, km, 1, km, synth.XX_MISS,
+                                      oh.data_ptr(), apply_pow10=True, ohscale=0.85, stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    booster.check()
+    info = booster.info()
+    algo = 4 * (23 * n_total + 4 * plane + n_total) + info["node_bytes"]
+    per_step = elapsed / args.steps
+    achieved = algo / per_step / 1e9
+    print(json.dumps({
+        "metric": "OH gridcells/sec (XGBoost predict), C360 L72 batch", "value": n_total / per_step,
+        "unit": "gridcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.grid} L{km}: fused SoA call, 27 MAPL fields in HBM -> 10**pred * OHscale",
+                   "grid": list(grid), "rows_total": n_total, "kernel": args.kernel, "params": args.param,
+                   "model": {"trees": info["num_trees"], "nodes": info["num_nodes"], "node_bytes": info["node_bytes"],
+                             "build_s": round(t_model, 2)}},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "predict_fields_kernel<2,2>",
+                     "kernel_ms": per_step * 1e3, "algorithmic_bytes": algo},
+        "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,9 +161,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("OHX_BENCH_FORCE_DIST") == "1"     # exercise the RCCL calls with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if force_dist and world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     from quickchem_amd import capi, shard, synth
@@ -138,6 +191,11 @@ def main():
         booster.set_param(name, val)
     t_model = time.perf_counter() - t0
 
+    if args.path == "fields":
+        if world != 1:
+            raise SystemExit("--path fields is a single-GPU measurement")
+        return bench_fields(args, grid, n_total, model, booster, dev, t_model)
+
     # ---- the batch: this rank's contiguous row shard, generated in HBM ----
     rows = torch.empty((n_local, synth.NFEAT), dtype=torch.float32, device=dev)
     synth.rows_device(grid, row0, n_local, rows)
@@ -151,7 +209,8 @@ def main():
     dmat = capi.DMatrix(device_ptr=rows.data_ptr(), nrow=n_local, ncol=synth.NFEAT, missing=synth.XX_MISS)
     out_local = torch.empty(n_local, dtype=torch.float32, device=dev)
     even = (n_total % world == 0)
-    out_full = torch.empty(n_total, dtype=torch.float32, device=dev) if world > 1 else out_local
+    gather = world > 1 or force_dist
+    out_full = torch.empty(n_total, dtype=torch.float32, device=dev) if gather else out_local
     stream = torch.cuda.current_stream()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -162,12 +221,12 @@ def main():
         booster.predict_device(dmat, out_local.data_ptr(), stream=stream.cuda_stream)
         if i is not None:
             ev1[i].record(stream)
-        if world > 1:
+        if gather:
             shard.all_gather_rows(out_full, out_local, n_total, world, even)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if gather:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -193,7 +252,7 @@ def main():
 
     info = booster.info()
     tiles = (n_local + 63) // 64
-    launches_per_step = -(-tiles // (256 * 20))     # one launch per residency of 256 CUs x 20 waves
+    launches_per_step = -(-tiles // (256 * 20 * 2))  # one launch per two residencies of 256 CUs x 20 waves
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total / (elapsed / args.steps)
     algo_bytes = BYTES_PER_CELL * n_local + info["node_bytes"]
@@ -206,7 +265,7 @@ def main():
         got = out_local[:n_chk].cpu().numpy()
         if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
             raise SystemExit("bench: GPU margins differ from the oracle on the cpu_baseline sample")
-    if world > 1:
+    if gather:
         # every rank must hold the whole field, and the shards in row order
         lo = out_full[row0:row0 + n_local]
         if not torch.equal(lo.view(torch.int32), out_local.view(torch.int32)):
@@ -241,7 +300,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if gather:
         dist.destroy_process_group()
 
 

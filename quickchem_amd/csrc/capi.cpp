@@ -554,6 +554,10 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     int k = atoi(value);
     if (k < 0 || k > 1000000) throw OhxError("ohx_launches_per_residency must be >= 0");
     b->tune.launches_per_residency = k;
+  } else if (n == "ohx_lds_pad") {
+    b->tune.lds_pad = atoi(value);
+  } else if (n == "ohx_prefetch") {
+    b->tune.prefetch = atoi(value) != 0;
   } else if (n == "ohx_xcd_remap") {
     b->tune.xcd_remap = atoi(value) != 0;
   } else if (n == "ohx_device") {
@@ -652,7 +656,7 @@ int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fie
   if (pick_kernel(*b) == KernelKind::Wide) ensure_wide(*b);
   if (a.k2 >= a.k1)
     HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus,
-                                    static_cast<hipStream_t>(stream)));
+                                    static_cast<hipStream_t>(stream), b->tune));
   API_END();
 }
 
@@ -689,7 +693,7 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
     a.margin_out = b->d_stage_margin.p;
   }
   if (pick_kernel(*b) == KernelKind::Wide) ensure_wide(*b);
-  HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus, nullptr));
+  HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus, nullptr, b->tune));
   HIP_CHECK(hipMemcpy(oh_ml + plane * (size_t)a.k1, b->d_stage_out.p, nrow * sizeof(float), hipMemcpyDeviceToHost));
   if (margin) HIP_CHECK(hipMemcpy(margin, b->d_stage_margin.p, nrow * sizeof(float), hipMemcpyDeviceToHost));
   raise_flag_errors(*b, nullptr);

@@ -95,6 +95,38 @@ __device__ __forceinline__ bool fill_tile_rows(float* __restrict__ tile, const f
   return any_nan;
 }
 
+// The OH shape (27 columns, 27 features): a row held in registers, so the NEXT tile's rows can
+// be in flight from HBM while the current tile is walked (the walk needs no registers of it).
+struct Row27 {
+  f4u v[6];
+  float t[3];
+};
+
+__device__ __forceinline__ void load_row27(Row27& r, const float* __restrict__ rows, uint64_t row) {
+  const float* p = rows + row * 27u;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) r.v[q] = __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p + 4 * q));
+#pragma unroll
+  for (int q = 0; q < 3; ++q) r.t[q] = __builtin_nontemporal_load(p + 24 + q);
+}
+
+__device__ __forceinline__ bool store_row27(float* __restrict__ tile, const Row27& r, bool valid, float missing,
+                                            bool missing_is_nan, uint32_t* flags) {
+  bool any_nan = false, any_inf = false;
+  const float qnan = __builtin_nanf("");
+#pragma unroll
+  for (int f = 0; f < 27; ++f) {
+    float x = f < 24 ? r.v[f / 4][f % 4] : r.t[f - 24];
+    if (!valid) x = 0.0f;
+    any_inf |= is_inf(x);
+    if (!missing_is_nan && x == missing) x = qnan;
+    any_nan |= (x != x);
+    tile[f * kWave] = x;
+  }
+  if (any_inf && !is_inf(missing) && flags) atomicOr(flags, kFlagInfInput);
+  return any_nan;
+}
+
 // ------------------------------------------------------------------ walks
 
 template <bool HAS_MISSING>
@@ -284,8 +316,9 @@ return wave_has_missing ? walk_super<CHAINS, true>(nodes, fr.super_heads, t0, t1
 
 // ------------------------------------------------------------------ kernels
 
-// AoS rows in, margins out.
-template <int FMT, int CHAINS>
+// AoS rows in, margins out.  PREFETCH27: 27-column rows, next tile's rows prefetched into
+// registers during the walk (used when a launch gives every wave more than one tile).
+template <int FMT, int CHAINS, bool PREFETCH27>
 __global__ __launch_bounds__(kBlock) void predict_rows_tile_kernel(DeviceForest fr, PredictArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -299,6 +332,29 @@ __global__ __launch_bounds__(kBlock) void predict_rows_tile_kernel(DeviceForest 
   if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const uint64_t wave_id = (uint64_t)block * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  if constexpr (PREFETCH27) {
+    uint64_t tile_id = a.tile_begin + wave_id;
+    Row27 regs;
+    if (tile_id < a.tile_end) {
+      const uint64_t row = tile_id * kWave + lane;
+      load_row27(regs, a.rows, row < a.nrow ? row : a.nrow - 1);
+    }
+    while (tile_id < a.tile_end) {
+      const uint64_t row = tile_id * kWave + lane;
+      const bool valid = row < a.nrow;
+      const bool lane_nan = store_row27(tile, regs, valid, a.missing, missing_is_nan, a.flags);
+      const uint64_t next = tile_id + nwaves;
+      if (next < a.tile_end) {
+        const uint64_t nrow = next * kWave + lane;
+        load_row27(regs, a.rows, nrow < a.nrow ? nrow : a.nrow - 1);   // in flight during the walk
+      }
+      const bool wave_nan = __any(lane_nan);
+      const float acc = walk_tile<FMT, CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
+      if (valid) __builtin_nontemporal_store(acc, a.out + row);
+      tile_id = next;
+    }
+    return;
+  }
   for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
     const uint64_t row = tile_id * kWave + lane;
     const bool valid = row < a.nrow;
@@ -360,11 +416,10 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
   const uint64_t nrow = plane * (uint64_t)(a.k2 - a.k1 + 1);
   const uint64_t slab = plane * (uint64_t)(a.k1 - a.src_k0);
   const uint64_t slab_out = plane * (uint64_t)(a.k1 - a.out_k0);
-  const uint64_t ntiles = (nrow + kWave - 1) / kWave;
   const uint64_t wave_id = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
   const float qnan = __builtin_nanf("");
-  for (uint64_t tile_id = wave_id; tile_id < ntiles; tile_id += nwaves) {
+  for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
     const uint64_t m = tile_id * kWave + lane;
     const bool valid = m < nrow;
     const uint64_t col = valid ? m % plane : 0;
@@ -497,6 +552,7 @@ hipError_t ensure_lds(K kernel, size_t lds_bytes) {
 template <class K>
 hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, PredictArgs a, int num_cus,
                              hipStream_t stream, const LaunchTuning& tune) {
+  lds += (size_t)tune.lds_pad;
   hipError_t e = ensure_lds(kernel, lds);
   if (e != hipSuccess) return e;
   const int grid = tile_grid(kernel, lds, a.nrow, num_cus);
@@ -549,18 +605,46 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
     else hipLaunchKernelGGL(predict_rows_direct_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, fr, a);
     return hipGetLastError();
   }
+  // every wave gets more than one tile per launch and the rows are the OH shape: prefetch
+  const bool pf = a.ncol == 27 && fr.num_feature == 27 && tune.launches_per_residency != 1 && tune.prefetch;
+#define OHX_ROWS(FMT, CH)                                                                                    \
+  return pf ? launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, true>, lds, fr, a, num_cus, stream, tune)   \
+            : launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, false>, lds, fr, a, num_cus, stream, tune)
   switch (kind) {
-    case KernelKind::Packed1: return launch_rows_tiled(predict_rows_tile_kernel<1, 1>, lds, fr, a, num_cus, stream, tune);
-    case KernelKind::Packed2: return launch_rows_tiled(predict_rows_tile_kernel<1, 2>, lds, fr, a, num_cus, stream, tune);
-    case KernelKind::Packed4: return launch_rows_tiled(predict_rows_tile_kernel<1, 4>, lds, fr, a, num_cus, stream, tune);
-    case KernelKind::Super1: return launch_rows_tiled(predict_rows_tile_kernel<2, 1>, lds, fr, a, num_cus, stream, tune);
-    case KernelKind::Super4: return launch_rows_tiled(predict_rows_tile_kernel<2, 4>, lds, fr, a, num_cus, stream, tune);
-    default: return launch_rows_tiled(predict_rows_tile_kernel<2, 2>, lds, fr, a, num_cus, stream, tune);
+    case KernelKind::Packed1: OHX_ROWS(1, 1);
+    case KernelKind::Packed2: OHX_ROWS(1, 2);
+    case KernelKind::Packed4: OHX_ROWS(1, 4);
+    case KernelKind::Super1: OHX_ROWS(2, 1);
+    case KernelKind::Super4: OHX_ROWS(2, 4);
+    default: OHX_ROWS(2, 2);
   }
+#undef OHX_ROWS
+}
+
+// Same train of launches as the row kernels: a launch per `launches_per_residency` residencies
+// keeps the waves of an XCD on the same few trees.
+template <class K>
+hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, FieldsArgs a, uint64_t nrow, int num_cus,
+                               hipStream_t stream, const LaunchTuning& tune) {
+  hipError_t e = ensure_lds(kernel, lds);
+  if (e != hipSuccess) return e;
+  const int grid = tile_grid(kernel, lds, nrow, num_cus);
+  const uint64_t ntiles = (nrow + kWave - 1) / kWave;
+  const uint64_t per_launch = tune.launches_per_residency <= 0
+                                  ? ntiles
+                                  : (uint64_t)grid * kWavesPerBlock * (uint64_t)tune.launches_per_residency;
+  for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
+    a.tile_begin = t0;
+    a.tile_end = t0 + per_launch < ntiles ? t0 + per_launch : ntiles;
+    const uint64_t blocks = (a.tile_end - a.tile_begin + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < (uint64_t)grid ? blocks : (uint64_t)grid)), dim3(kBlock), lds,
+                       stream, fr, a);
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const FieldsArgs& a, int num_cus,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, const LaunchTuning& tune) {
   if (a.k2 < a.k1 || a.im <= 0 || a.jm <= 0) return hipSuccess;
   const uint64_t nrow = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)(a.k2 - a.k1 + 1);
   const size_t lds = tile_lds_bytes(fr.num_feature);
@@ -569,14 +653,8 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
   const bool use_wide = kind == KernelKind::Wide || (!is_super && fr.packed == nullptr);
   if (use_wide && fr.wide == nullptr) return hipErrorInvalidValue;
-#define OHX_LAUNCH_FIELDS(FMT, CH)                                                                       \
-  do {                                                                                                   \
-    hipError_t e = ensure_lds(predict_fields_kernel<FMT, CH>, lds);                                      \
-    if (e != hipSuccess) return e;                                                                       \
-    const int grid = tile_grid(predict_fields_kernel<FMT, CH>, lds, nrow, num_cus);                      \
-    hipLaunchKernelGGL((predict_fields_kernel<FMT, CH>), dim3(grid), dim3(kBlock), lds, stream, fr, a);  \
-    return hipGetLastError();                                                                            \
-  } while (0)
+#define OHX_LAUNCH_FIELDS(FMT, CH) \
+  return launch_fields_tiled(predict_fields_kernel<FMT, CH>, lds, fr, a, nrow, num_cus, stream, tune)
   if (use_wide) OHX_LAUNCH_FIELDS(0, 1);
   switch (kind) {
     case KernelKind::Packed1: OHX_LAUNCH_FIELDS(1, 1);

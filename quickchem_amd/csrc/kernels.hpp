@@ -47,8 +47,10 @@ struct LaunchTuning {
   // 0: one launch for the whole batch (waves stride over tiles).  > 0: one launch per this many
   // "waves of tiles": every launch starts all resident waves on tree 0 together, so the waves of
   // an XCD walk the same few trees at the same time and share their node lines in that XCD's L2.
-  int launches_per_residency = 1;
+  int launches_per_residency = 2;
   int xcd_remap = 1;
+  int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
+  int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
 };
 
 // 27 SoA fields of the MAPL state (OH_GridCompMod.F90:313-339), device pointers.
@@ -67,6 +69,7 @@ struct FieldsArgs {
   float* out = nullptr;        // (im,jm,km) array; only levels k1..k2 are written
   float* margin_out = nullptr; // optional [N] raw margins in slab row order
   uint32_t* flags = nullptr;
+  uint64_t tile_begin = 0, tile_end = 0;   // 64-row tiles of this launch
 };
 
 enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super4 };
@@ -76,7 +79,7 @@ const char* kernel_kind_name(KernelKind k);
 hipError_t launch_predict(KernelKind kind, const DeviceForest& forest, const PredictArgs& a, int num_cus,
                           hipStream_t stream, const LaunchTuning& tune = LaunchTuning());
 hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& forest, const FieldsArgs& a, int num_cus,
-                                 hipStream_t stream);
+                                 hipStream_t stream, const LaunchTuning& tune = LaunchTuning());
 hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream);
 
 // synthetic inputs (synth_common.h), generated in HBM

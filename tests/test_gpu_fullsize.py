@@ -59,3 +59,32 @@ def test_full_size_properties(full_model, gridname, shard):
     want = helpers.oracle_predict(full_model.image, sample, synth.XX_MISS)
     assert np.array_equal(helpers.bits(a[idx].cpu().numpy()), helpers.bits(want))
     assert torch.isfinite(a).all() and -16 < float(a.min()) and float(a.max()) < -10
+
+
+def test_c720_l137_shard_with_twelve_resident_boosters():
+    """BASELINE.json config #5: one of the 8 row shards of C720 L137 (53 265 600 gridcells, 5.75 GB of
+    features) with twelve monthly boosters resident in HBM at once (the reference keeps one booster per
+    process and never reloads on month roll-over, OH_GridCompMod.F90:209,269; OH_instance_OH.rc:20)."""
+    import torch
+    torch.cuda.set_device(0)
+    grid = synth.GRIDS["C720L137"]
+    n = grid[0] * grid[1] * grid[2] // 8
+    assert n == 53_265_600
+    rows = torch.empty((n, 27), dtype=torch.float32, device="cuda")
+    synth.rows_device(grid, 5 * n, n, rows)
+    models = [synth.make_model(sample_log2=18, min_leaf=4, model_seed=synth.MODEL_SEED + 100 * m) for m in range(12)]
+    boosters = [capi.Booster(model_buffer=m.image) for m in models]
+    idx = torch.randint(0, n, (20_000,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    sample = rows[idx].cpu().numpy()
+    first = None
+    for month in (0, 6, 11, 0):
+        out = _predict_dev(torch, boosters[month], rows, "auto")
+        want = helpers.oracle_predict(models[month].image, sample, synth.XX_MISS)
+        assert np.array_equal(helpers.bits(out[idx].cpu().numpy()), helpers.bits(want)), month
+        if month == 0:
+            if first is None:
+                first = out.clone()
+            else:
+                assert torch.equal(first.view(torch.int32), out.view(torch.int32))   # other boosters did not disturb it
+    # different months really are different models
+    assert not torch.equal(first.view(torch.int32), _predict_dev(torch, boosters[6], rows, "auto").view(torch.int32))
