@@ -93,9 +93,10 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
                      bst_ulong* out_len, const float** out_result);
 
 /* xgboost c_api.h; not bound by the reference.  Understood names:
- *   "ohx_kernel"      wide | packed1 | packed2 | packed4 (default packed4)
- *   "ohx_top_levels"  breadth-first levels per tree before line packing
- *   "ohx_line_slots"  node slots per packed line (0 = breadth-first only)
+ *   "ohx_kernel"      auto (= super2) | super1 | super2 | super4 | packed1 | packed2 |
+ *                     packed4 | wide : node format and trees in flight per lane
+ *   "ohx_launches_per_residency"  tiles per wave per launch (default 2; 0 = one launch)
+ *   "ohx_top_levels", "ohx_line_slots", "ohx_min_chunk"  placement of the packed format
  *   "ohx_device"      HIP device ordinal for this booster
  * xgboost's own parameter names ("nthread", "predictor", ...) are accepted and
  * ignored. */
@@ -139,6 +140,53 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
 int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fields[], const int32_t is2d[],
                                   int nfield, int pl_feature, int im, int jm, int km, int k1, int k2, float missing,
                                   int apply_pow10, float ohscale, float* d_oh_ml, float* d_margin, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Part 3 — the steps either side of the predict call (additive)
+ * ------------------------------------------------------------------------
+ * OHXBoosterRun1 does the arithmetic of OH Run1 from the imports to the INTERNAL
+ * field OH (OH_GridComp/OH_GridCompMod.F90:1240-1257, 1444-1478, 1488, 1557-1595)
+ * in HBM, so the engineered features never round-trip to the host:
+ *   PL_MOD = (PLE_MOD(k-1)+PLE_MOD(k))*0.5, TV_MOD, NDWET_MOD            (:1247-1257)
+ *   stratO3 = GMITO3 - GMITTO3                                           (:1446)
+ *   gridBoxThickness = ZLE(k-1)-ZLE(k); aod = thickness * (BC+OC+BR+DU+SU+SS+NI)   (:1451-1458)
+ *   tauclwDN/taucliDN/aodDN(k) = SUM(x(k:km)), taucliUP/tauclwUP/aodUP(k) = SUM(x(1:k)),
+ *       each sum accumulated from zero in ascending level order          (:1468-1478)
+ *   PL_BST = (PLE_BST(k-1)+PLE_BST(k))*0.5                               (:1488)
+ *   the k-slab, predict_OH_with_XGB, OH_ML *= OHscale                    (:1559-1569)
+ *   OH = PL_MOD > TROPP ? OH_ML : default_OH ; OH = (OH*NDWET_MOD)*1.0e-6   (:1579-1595)
+ * What stays with the caller: the choice of import per OH_data_source, LAT in
+ * degrees, and the local-noon SZA (:401-466; 2-D, libm-bound).
+ * All arrays are Fortran order: 3-D (im,jm,km), edge fields (im,jm,0:km), 2-D
+ * (im,jm).  MAPL's constants are passed in, not restated.  Host form stages
+ * through HBM and returns when the outputs are complete; device form takes device
+ * pointers and enqueues (it synchronises the stream once, to read the slab). */
+typedef struct OHXRun1Args {
+  int32_t im, jm, km;
+  int32_t dynamic_k_range;           /* .NOT. compute_once_per_day (:1561) */
+  float tropp_min;                   /* Pa, 4000.0 (:1563) */
+  float ohscale;                     /* :1569 */
+  float missing;                     /* -999.0 (:213) */
+  float avogad, runiv, epsilon;      /* MAPL_AVOGAD, MAPL_RUNIV, MAPL_EPSILON */
+  /* the model's own state: slab, tropopause mask, number density */
+  const float *ple_mod, *t_mod, *q_mod, *tropp_mod;
+  /* inputs to the engineered features */
+  const float *ple_bst, *zle_bst, *tauclw, *taucli;
+  const float *scacoef[7];           /* BC OC BR DU SU SS NI at the chosen wavelength */
+  const float *gmito3, *gmitto3;
+  /* features used as they are (order of :313-339 where not engineered) */
+  const float *lat_deg, *t_bst, *no2, *o3, *ch4, *co, *isop, *acet, *c2h6, *c3h8, *prpe, *alk4, *mp, *h2o2;
+  const float *cloud, *qv, *albuv, *ch2o, *sza;
+  const float *default_oh;           /* import oh_OH, mol/mol (:1548) */
+  /* outputs */
+  float *oh;                         /* INTERNAL OH, molec/cm3 */
+  float *oh_boost;                   /* export OH_boost = OH_ML*OHscale (may be NULL) */
+  float *ndwet;                      /* DIAG_NDWET (may be NULL) */
+  int32_t *k1, *k2;                  /* HOST pointers, 1-based slab (may be NULL) */
+} OHXRun1Args;
+
+int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args);
+int OHXBoosterRun1Device(BoosterHandle handle, const OHXRun1Args* args, void* stream);
 
 /* Model facts for roofline accounting: info[0] trees, [1] nodes in the model,
  * [2] node slots in HBM, [3] bytes of the node array the selected kernel reads,

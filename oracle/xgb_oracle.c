@@ -499,3 +499,86 @@ ORACLE_EXPORT int OHXBoosterPredictFields(void* booster, const float* const fiel
   free(xx_carr);
   return rc;
 }
+
+/*
+ * CPU restatement of OH Run1's arithmetic from the imports to the INTERNAL field OH
+ * (OH_GridCompMod.F90:1240-1257, 1444-1478, 1488, 1557-1595), same argument record as the
+ * product's OHXBoosterRun1 (include/ohxgb.h part 3).  Every SUM(x(a:b)) is accumulated from
+ * zero in ascending level order; every expression is evaluated in the order the Fortran
+ * source writes it, in float.
+ */
+typedef struct {
+  int32_t im, jm, km;
+  int32_t dynamic_k_range;
+  float tropp_min, ohscale, missing;
+  float avogad, runiv, epsilon;
+  const float *ple_mod, *t_mod, *q_mod, *tropp_mod;
+  const float *ple_bst, *zle_bst, *tauclw, *taucli;
+  const float *scacoef[7];
+  const float *gmito3, *gmitto3;
+  const float *lat_deg, *t_bst, *no2, *o3, *ch4, *co, *isop, *acet, *c2h6, *c3h8, *prpe, *alk4, *mp, *h2o2;
+  const float *cloud, *qv, *albuv, *ch2o, *sza;
+  const float *default_oh;
+  float *oh, *oh_boost, *ndwet;
+  int32_t *k1, *k2;
+} OracleRun1Args;
+
+ORACLE_EXPORT int OHXBoosterRun1(void* booster, const OracleRun1Args* a) {
+  const int im = a->im, jm = a->jm, km = a->km;
+  const size_t plane = (size_t)im * (size_t)jm, vol = plane * (size_t)km;
+  float* buf = (float*)malloc((10 * vol + plane) * sizeof(float));
+  float *pl_mod = buf, *pl_bst = buf + vol, *tauclwdn = buf + 2 * vol, *tauclidn = buf + 3 * vol;
+  float *taucliup = buf + 4 * vol, *tauclwup = buf + 5 * vol, *aod = buf + 6 * vol, *aodup = buf + 7 * vol;
+  float *aoddn = buf + 8 * vol, *oh_ml = buf + 9 * vol, *strato3 = buf + 10 * vol;
+  for (size_t m = 0; m < vol; ++m) {
+    pl_mod[m] = (a->ple_mod[m] + a->ple_mod[m + plane]) * 0.5f;                 /* :1247 */
+    pl_bst[m] = (a->ple_bst[m] + a->ple_bst[m + plane]) * 0.5f;                 /* :1488 */
+    const float thick = a->zle_bst[m] - a->zle_bst[m + plane];                  /* :1451 */
+    float sc = a->scacoef[0][m] + a->scacoef[1][m];                             /* :1456-1457 */
+    for (int i = 2; i < 7; ++i) sc = sc + a->scacoef[i][m];
+    aod[m] = thick * sc;
+  }
+  for (size_t c = 0; c < plane; ++c) strato3[c] = a->gmito3[c] - a->gmitto3[c]; /* :1446 */
+  for (int k = 0; k < km; ++k)                                                   /* :1468-1478 */
+    for (size_t c = 0; c < plane; ++c) {
+      float wdn = 0.0f, idn = 0.0f, iup = 0.0f, wup = 0.0f, aup = 0.0f, adn = 0.0f;
+      for (int kk = k; kk < km; ++kk) {
+        wdn = wdn + a->tauclw[c + plane * (size_t)kk];
+        idn = idn + a->taucli[c + plane * (size_t)kk];
+        adn = adn + aod[c + plane * (size_t)kk];
+      }
+      for (int kk = 0; kk <= k; ++kk) {
+        iup = iup + a->taucli[c + plane * (size_t)kk];
+        wup = wup + a->tauclw[c + plane * (size_t)kk];
+        aup = aup + aod[c + plane * (size_t)kk];
+      }
+      const size_t m = c + plane * (size_t)k;
+      tauclwdn[m] = wdn; tauclidn[m] = idn; taucliup[m] = iup; tauclwup[m] = wup; aodup[m] = aup; aoddn[m] = adn;
+    }
+  memset(oh_ml, 0, vol * sizeof(float));                                         /* :1559 */
+  const float* fields[27] = {a->lat_deg, pl_bst, a->t_bst, a->no2, a->o3, a->ch4, a->co, a->isop, a->acet, a->c2h6,
+                             a->c3h8, a->prpe, a->alk4, a->mp, a->h2o2, tauclwdn, tauclidn, taucliup, tauclwup,
+                             a->cloud, a->qv, strato3, a->albuv, aodup, aoddn, a->ch2o, a->sza};
+  static const int32_t is2d[27] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};
+  /* bb%PL is PL_BST in Pa: predict_OH_with_XGB divides by 100 (:314); the slab uses PL_MOD (:1565) */
+  int k1 = 0, k2 = 0;
+  int rc = oracle_predict_OH_with_XGB(booster, im, jm, km, a->dynamic_k_range, a->tropp_min, pl_mod, a->tropp_mod,
+                                      fields, is2d, oh_ml, NULL, &k1, &k2);
+  if (rc == 0) {
+    if (a->k1) *a->k1 = k1;
+    if (a->k2) *a->k2 = k2;
+    for (size_t m = 0; m < vol; ++m) oh_ml[m] = oh_ml[m] * a->ohscale;          /* :1569 */
+    if (a->oh_boost) memcpy(a->oh_boost, oh_ml, vol * sizeof(float));           /* :1571-1572 */
+    for (size_t m = 0; m < vol; ++m) {
+      const size_t c = m % plane;
+      const float q = a->q_mod[m];
+      const float tv = a->t_mod[m] * (1.0f + q / a->epsilon) / (1.0f + q);     /* :1250 */
+      const float ndwet = (a->avogad * pl_mod[m]) / (a->runiv * tv);           /* :1257 */
+      const float ohv = (pl_mod[m] > a->tropp_mod[c]) ? oh_ml[m] : a->default_oh[m];   /* :1579-1587 */
+      a->oh[m] = (ohv * ndwet) * 1.0e-6f;                                       /* :1595 */
+      if (a->ndwet) a->ndwet[m] = ndwet;
+    }
+  }
+  free(buf);
+  return rc;
+}

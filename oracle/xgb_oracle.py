@@ -233,3 +233,56 @@ def predict_OH_with_XGB(model: OracleModel, pl: np.ndarray, tropp: np.ndarray, f
     oh = np.power(np.float32(10.0), margin, dtype=np.float32)          # :369
     oh_ml[:, :, k1 - 1:k2] = np.transpose(oh.reshape(nlev, jm, im), (2, 1, 0))
     return oh_ml, margin, k1, k2
+
+
+# --------------------------------------------------------------------- OH Run1, either side of the call
+
+def run1(model: OracleModel, st: dict, dynamic_k_range: bool, tropp_min: float = 4000.0, ohscale: float = 0.85,
+         avogad: float = 6.023e26, runiv: float = 8314.47, epsilon: float = 18.015 / 28.965):
+    """OH Run1 from the imports to INTERNAL OH (OH_GridCompMod.F90:1240-1257, 1444-1478, 1488,
+    1557-1595).  `st` maps the names of include/ohxgb.h's OHXRun1Args to [i,j(,k)] float32 arrays.
+    Every SUM is accumulated from zero, ascending in the level index, one float add at a time."""
+    f32 = np.float32
+    km = st["t_mod"].shape[2]
+    ple_mod, ple_bst, zle = (np.asarray(st[k], dtype=f32) for k in ("ple_mod", "ple_bst", "zle_bst"))
+    pl_mod = ((ple_mod[:, :, :-1] + ple_mod[:, :, 1:]) * f32(0.5)).astype(f32)              # :1247
+    pl_bst = ((ple_bst[:, :, :-1] + ple_bst[:, :, 1:]) * f32(0.5)).astype(f32)              # :1488
+    thick = (zle[:, :, :-1] - zle[:, :, 1:]).astype(f32)                                    # :1451
+    sc = (st["scacoef"][0] + st["scacoef"][1]).astype(f32)                                  # :1456-1457
+    for i in range(2, 7):
+        sc = (sc + st["scacoef"][i]).astype(f32)
+    aod = (thick * sc).astype(f32)
+    strato3 = (st["gmito3"] - st["gmitto3"]).astype(f32)                                    # :1446
+
+    def sum_up(x):     # SUM(x(1:k))
+        out = np.empty_like(x)
+        acc = np.zeros(x.shape[:2], dtype=f32)
+        for k in range(km):
+            acc = (acc + x[:, :, k]).astype(f32)
+            out[:, :, k] = acc
+        return out
+
+    def sum_dn(x):     # SUM(x(k:km)), each from zero
+        out = np.empty_like(x)
+        for k in range(km):
+            acc = np.zeros(x.shape[:2], dtype=f32)
+            for kk in range(k, km):
+                acc = (acc + x[:, :, kk]).astype(f32)
+            out[:, :, k] = acc
+        return out
+
+    tauclw, taucli = np.asarray(st["tauclw"], dtype=f32), np.asarray(st["taucli"], dtype=f32)
+    fields = [st["lat_deg"], pl_bst, st["t_bst"], st["no2"], st["o3"], st["ch4"], st["co"], st["isop"], st["acet"],
+              st["c2h6"], st["c3h8"], st["prpe"], st["alk4"], st["mp"], st["h2o2"], sum_dn(tauclw), sum_dn(taucli),
+              sum_up(taucli), sum_up(tauclw), st["cloud"], st["qv"], strato3, st["albuv"], sum_up(aod), sum_dn(aod),
+              st["ch2o"], st["sza"]]                                                        # :313-339
+    fields = [np.asarray(a, dtype=f32) for a in fields]
+    oh_ml, margin, k1, k2 = predict_OH_with_XGB(model, pl_mod, np.asarray(st["tropp_mod"], dtype=f32), fields,
+                                                dynamic_k_range, tropp_min)
+    oh_ml = (oh_ml * f32(ohscale)).astype(f32)                                              # :1569
+    q, t = np.asarray(st["q_mod"], dtype=f32), np.asarray(st["t_mod"], dtype=f32)
+    tv = ((t * (f32(1.0) + q / f32(epsilon))).astype(f32) / (f32(1.0) + q)).astype(f32)     # :1250
+    ndwet = ((f32(avogad) * pl_mod).astype(f32) / (f32(runiv) * tv).astype(f32)).astype(f32)   # :1257
+    ohv = np.where(pl_mod > np.asarray(st["tropp_mod"], dtype=f32)[:, :, None], oh_ml, st["default_oh"]).astype(f32)
+    oh = ((ohv * ndwet).astype(f32) * f32(1.0e-6)).astype(f32)                              # :1595
+    return {"oh": oh, "oh_boost": oh_ml, "ndwet": ndwet, "k1": k1, "k2": k2, "fields": fields, "margin": margin}

@@ -23,7 +23,8 @@ ABI_SYMBOLS = [
     "XGDMatrixSaveBinary", "XGDMatrixCreateFromFile", "XGBoosterCreate", "XGBoosterFree", "XGBoosterLoadModel",
     "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXBoosterPredictDevice", "OHXBoosterCheck",
-    "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterGetInfo", "OHXSynthRowsDevice",
+    "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device",
+    "OHXBoosterGetInfo", "OHXSynthRowsDevice",
     "OHXSynthFieldDevice", "OHXInjectMissingDevice",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
@@ -36,6 +37,26 @@ REFERENCE_BOUND_SYMBOLS = [
 
 class OhxError(RuntimeError):
     pass
+
+
+class OHXRun1Args(C.Structure):
+    """struct OHXRun1Args of include/ohxgb.h (part 3)."""
+    _P = C.c_void_p
+    _fields_ = ([("im", C.c_int32), ("jm", C.c_int32), ("km", C.c_int32), ("dynamic_k_range", C.c_int32),
+                 ("tropp_min", C.c_float), ("ohscale", C.c_float), ("missing", C.c_float),
+                 ("avogad", C.c_float), ("runiv", C.c_float), ("epsilon", C.c_float)] +
+                [(n, C.c_void_p) for n in ("ple_mod", "t_mod", "q_mod", "tropp_mod", "ple_bst", "zle_bst", "tauclw",
+                                           "taucli")] +
+                [("scacoef", C.c_void_p * 7)] +
+                [(n, C.c_void_p) for n in ("gmito3", "gmitto3", "lat_deg", "t_bst", "no2", "o3", "ch4", "co", "isop",
+                                           "acet", "c2h6", "c3h8", "prpe", "alk4", "mp", "h2o2", "cloud", "qv", "albuv",
+                                           "ch2o", "sza", "default_oh", "oh", "oh_boost", "ndwet", "k1", "k2")])
+
+
+RUN1_INPUTS_3D = ["t_mod", "q_mod", "tauclw", "taucli", "t_bst", "no2", "o3", "ch4", "co", "isop", "acet", "c2h6", "c3h8",
+                  "prpe", "alk4", "mp", "h2o2", "cloud", "qv", "ch2o", "default_oh"]
+RUN1_INPUTS_EDGE = ["ple_mod", "ple_bst", "zle_bst"]
+RUN1_INPUTS_2D = ["tropp_mod", "gmito3", "gmitto3", "lat_deg", "albuv", "sza"]
 
 
 _lib: Optional[C.CDLL] = None
@@ -79,6 +100,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                                             f32, i32, f32, vp, vp]
     lib.OHXBoosterPredictFieldsDevice.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), i32, i32, i32, i32, i32,
                                                   i32, i32, f32, i32, f32, vp, vp, vp]
+    lib.OHXBoosterRun1.argtypes = [vp, C.POINTER(OHXRun1Args)]
+    lib.OHXBoosterRun1Device.argtypes = [vp, C.POINTER(OHXRun1Args), vp]
     lib.OHXBoosterGetInfo.argtypes = [vp, C.POINTER(u64)]
     lib.OHXSynthRowsDevice.argtypes = [u32, i32, i32, i32, u64, u64, vp, vp]
     lib.OHXSynthFieldDevice.argtypes = [u32, i32, i32, i32, i32, vp, vp]
@@ -218,6 +241,40 @@ class Booster:
         check(self.lib, self.lib.OHXBoosterPredictFieldsDevice(
             self.handle, ptrs, flags, nf, pl_feature, im, jm, km, k1, k2, missing, 1 if apply_pow10 else 0, ohscale,
             oh_ml_ptr, margin_ptr or None, stream or None))
+
+    def run1(self, state: dict, *, dynamic_k_range: bool, tropp_min: float = 4000.0, ohscale: float = 0.85,
+             missing: float = -999.0, avogad: float = 6.023e26, runiv: float = 8314.47,
+             epsilon: float = 18.015 / 28.965, want_boost: bool = True, want_ndwet: bool = True) -> dict:
+        """OHXBoosterRun1 on host arrays.  `state` maps the names of OHXRun1Args to [i,j(,k)]-indexed
+        float32 arrays (edge fields have km+1 levels; "scacoef" is a list of seven).  Returns
+        {"oh", "oh_boost", "ndwet", "k1", "k2"} with arrays indexed [i,j,k]."""
+        def flat(a):
+            return np.ascontiguousarray(np.asarray(a, dtype=np.float32).T)
+        im, jm, km = state["t_mod"].shape
+        keep = {}
+        args = OHXRun1Args()
+        args.im, args.jm, args.km = im, jm, km
+        args.dynamic_k_range = 1 if dynamic_k_range else 0
+        args.tropp_min, args.ohscale, args.missing = tropp_min, ohscale, missing
+        args.avogad, args.runiv, args.epsilon = avogad, runiv, epsilon
+        for name in RUN1_INPUTS_3D + RUN1_INPUTS_EDGE + RUN1_INPUTS_2D:
+            keep[name] = flat(state[name])
+            setattr(args, name, keep[name].ctypes.data)
+        sca = [flat(a) for a in state["scacoef"]]
+        keep["sca"] = sca
+        args.scacoef = (C.c_void_p * 7)(*[a.ctypes.data for a in sca])
+        oh = np.zeros(im * jm * km, dtype=np.float32)
+        boost = np.zeros(im * jm * km, dtype=np.float32) if want_boost else None
+        ndwet = np.zeros(im * jm * km, dtype=np.float32) if want_ndwet else None
+        k1, k2 = C.c_int32(), C.c_int32()
+        args.oh = oh.ctypes.data
+        args.oh_boost = boost.ctypes.data if want_boost else None
+        args.ndwet = ndwet.ctypes.data if want_ndwet else None
+        args.k1 = C.cast(C.pointer(k1), C.c_void_p)
+        args.k2 = C.cast(C.pointer(k2), C.c_void_p)
+        check(self.lib, self.lib.OHXBoosterRun1(self.handle, C.byref(args)))
+        unflat = lambda a: None if a is None else a.reshape(km, jm, im).transpose(2, 1, 0)   # noqa: E731
+        return {"oh": unflat(oh), "oh_boost": unflat(boost), "ndwet": unflat(ndwet), "k1": k1.value, "k2": k2.value}
 
     def info(self) -> dict:
         arr = (C.c_uint64 * 8)()

@@ -162,6 +162,10 @@ struct BoosterObj {
   PinnedBuf<float> h_pred;
   std::vector<DevBuf<float>> d_stage;  // fused host path: per-field staging
   DevBuf<float> d_stage_out, d_stage_margin;
+  // Run1: engineered features, OH_ML and the slab result stay in HBM between the steps
+  DevBuf<float> d_run1[9];
+  DevBuf<int32_t> d_slab;
+  std::vector<DevBuf<float>> d_run1_stage;
 };
 
 DMatrixObj* as_dmat(DMatrixHandle h) {
@@ -696,6 +700,147 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
   HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus, nullptr, b->tune));
   HIP_CHECK(hipMemcpy(oh_ml + plane * (size_t)a.k1, b->d_stage_out.p, nrow * sizeof(float), hipMemcpyDeviceToHost));
   if (margin) HIP_CHECK(hipMemcpy(margin, b->d_stage_margin.p, nrow * sizeof(float), hipMemcpyDeviceToHost));
+  raise_flag_errors(*b, nullptr);
+  API_END();
+}
+
+static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream) {
+  if (r.im <= 0 || r.jm <= 0 || r.km <= 0) throw OhxError("OHXBoosterRun1: im, jm, km must be positive");
+  if (b.forest.num_feature != 27) throw OhxError("OHXBoosterRun1 needs the 27-feature OH booster");
+  const void* need[] = {r.ple_mod, r.t_mod, r.q_mod, r.tropp_mod, r.ple_bst, r.zle_bst, r.tauclw, r.taucli,
+                        r.gmito3, r.gmitto3, r.lat_deg, r.t_bst, r.no2, r.o3, r.ch4, r.co, r.isop, r.acet,
+                        r.c2h6, r.c3h8, r.prpe, r.alk4, r.mp, r.h2o2, r.cloud, r.qv, r.albuv, r.ch2o, r.sza,
+                        r.default_oh, r.oh};
+  for (const void* p : need)
+    if (p == nullptr) throw OhxError("OHXBoosterRun1: a required field pointer is NULL");
+  for (int i = 0; i < 7; ++i)
+    if (r.scacoef[i] == nullptr) throw OhxError("OHXBoosterRun1: a scattering-coefficient pointer is NULL");
+  const size_t plane = (size_t)r.im * (size_t)r.jm, vol = plane * (size_t)r.km;
+  for (int i = 0; i < 8; ++i) b.d_run1[i].ensure(i == 7 ? plane : vol);
+  b.d_run1[8].ensure(vol);
+  b.d_slab.ensure(2);
+  float* pl_bst = b.d_run1[0].p;
+  float *tauclwdn = b.d_run1[1].p, *tauclidn = b.d_run1[2].p, *taucliup = b.d_run1[3].p, *tauclwup = b.d_run1[4].p;
+  float *aodup = b.d_run1[5].p, *aoddn = b.d_run1[6].p, *strato3 = b.d_run1[7].p;
+  float* oh_ml = r.oh_boost ? r.oh_boost : b.d_run1[8].p;
+
+  PrepArgs pa;
+  pa.im = r.im; pa.jm = r.jm; pa.km = r.km;
+  pa.ple_bst = r.ple_bst; pa.zle_bst = r.zle_bst; pa.tauclw = r.tauclw; pa.taucli = r.taucli;
+  for (int i = 0; i < 7; ++i) pa.sca[i] = r.scacoef[i];
+  pa.gmito3 = r.gmito3; pa.gmitto3 = r.gmitto3;
+  pa.pl_bst = pl_bst; pa.tauclwdn = tauclwdn; pa.tauclidn = tauclidn; pa.taucliup = taucliup; pa.tauclwup = tauclwup;
+  pa.aodup = aodup; pa.aoddn = aoddn; pa.strato3 = strato3;
+  HIP_CHECK(launch_feature_prep(pa, stream));
+
+  SlabArgs sa;
+  sa.im = r.im; sa.jm = r.jm; sa.km = r.km;
+  sa.dynamic_k_range = r.dynamic_k_range; sa.tropp_min = r.tropp_min;
+  sa.ple_mod = r.ple_mod; sa.tropp = r.tropp_mod; sa.result = b.d_slab.p;
+  HIP_CHECK(hipMemsetAsync(b.d_slab.p, 0, 2 * sizeof(int32_t), stream));
+  HIP_CHECK(launch_k_slab(sa, stream));
+  int32_t slab[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(slab, b.d_slab.p, sizeof slab, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  if (!r.dynamic_k_range && slab[1] != 0)
+    throw OhxError("OH Prediction: Minimum tropopause pressure is not low enough!");
+  const int k1 = r.km - slab[0] + 1, k2 = r.km;   // 1-based (:300-301)
+  if (r.k1) *r.k1 = k1;
+  if (r.k2) *r.k2 = k2;
+
+  HIP_CHECK(hipMemsetAsync(oh_ml, 0, vol * sizeof(float), stream));          // self%OH_ML(:,:,:) = 0.0 (:1559)
+  const float* fields[27] = {r.lat_deg, pl_bst, r.t_bst, r.no2, r.o3, r.ch4, r.co, r.isop, r.acet, r.c2h6, r.c3h8,
+                             r.prpe, r.alk4, r.mp, r.h2o2, tauclwdn, tauclidn, taucliup, tauclwup, r.cloud, r.qv,
+                             strato3, r.albuv, aodup, aoddn, r.ch2o, r.sza};      // order of :313-339
+  static const int32_t is2d[27] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};
+  if (k2 >= k1) {
+    FieldsArgs fa{};
+    fa.is2d_mask = 0;
+    for (int f = 0; f < 27; ++f) {
+      fa.field[f] = fields[f];
+      if (is2d[f]) fa.is2d_mask |= (1u << f);
+    }
+    fa.pl_feature = 1;
+    fa.nfield = 27;
+    fa.im = r.im; fa.jm = r.jm; fa.km = r.km;
+    fa.k1 = k1 - 1; fa.k2 = k2 - 1;
+    fa.missing = r.missing;
+    tree_range(b, 0, &fa.tree_begin, &fa.tree_end);
+    fa.apply_pow10 = 1;
+    fa.scale = r.ohscale;
+    fa.out = oh_ml;
+    fa.flags = b.d_flags.p;
+    if (pick_kernel(b) == KernelKind::Wide) ensure_wide(b);
+    HIP_CHECK(launch_predict_fields(pick_kernel(b), device_forest(b), fa, b.dev.num_cus, stream, b.tune));
+  }
+  PostArgs po;
+  po.im = r.im; po.jm = r.jm; po.km = r.km;
+  po.avogad = r.avogad; po.runiv = r.runiv; po.epsilon = r.epsilon;
+  po.ple_mod = r.ple_mod; po.t_mod = r.t_mod; po.q_mod = r.q_mod; po.tropp = r.tropp_mod;
+  po.default_oh = r.default_oh; po.oh_ml = oh_ml; po.oh = r.oh; po.ndwet = r.ndwet;
+  HIP_CHECK(launch_post_process(po, stream));
+}
+
+int OHXBoosterRun1Device(BoosterHandle handle, const OHXRun1Args* args, void* stream) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (args == nullptr) throw OhxError("OHXBoosterRun1Device: args is NULL");
+  if (!objective_is_identity(b->forest.objective))
+    throw OhxError("objective '" + b->forest.objective + "' is not supported by OHXBoosterRun1");
+  ensure_uploaded(*b);
+  run1_device(*b, *args, static_cast<hipStream_t>(stream));
+  API_END();
+}
+
+int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (args == nullptr) throw OhxError("OHXBoosterRun1: args is NULL");
+  if (!objective_is_identity(b->forest.objective))
+    throw OhxError("objective '" + b->forest.objective + "' is not supported by OHXBoosterRun1");
+  ensure_uploaded(*b);
+  const OHXRun1Args& h = *args;
+  if (h.im <= 0 || h.jm <= 0 || h.km <= 0) throw OhxError("OHXBoosterRun1: im, jm, km must be positive");
+  const size_t plane = (size_t)h.im * (size_t)h.jm, vol = plane * (size_t)h.km, edge = plane * (size_t)(h.km + 1);
+  OHXRun1Args d = h;
+  // every input goes to HBM once; 43 slots: 41 inputs + OH + NDWET (OH_boost reuses the scratch OH_ML)
+  struct In { const float* host; const float** dev; size_t n; };
+  In ins[] = {
+      {h.ple_mod, &d.ple_mod, edge}, {h.t_mod, &d.t_mod, vol}, {h.q_mod, &d.q_mod, vol}, {h.tropp_mod, &d.tropp_mod, plane},
+      {h.ple_bst, &d.ple_bst, edge}, {h.zle_bst, &d.zle_bst, edge}, {h.tauclw, &d.tauclw, vol}, {h.taucli, &d.taucli, vol},
+      {h.scacoef[0], &d.scacoef[0], vol}, {h.scacoef[1], &d.scacoef[1], vol}, {h.scacoef[2], &d.scacoef[2], vol},
+      {h.scacoef[3], &d.scacoef[3], vol}, {h.scacoef[4], &d.scacoef[4], vol}, {h.scacoef[5], &d.scacoef[5], vol},
+      {h.scacoef[6], &d.scacoef[6], vol}, {h.gmito3, &d.gmito3, plane}, {h.gmitto3, &d.gmitto3, plane},
+      {h.lat_deg, &d.lat_deg, plane}, {h.t_bst, &d.t_bst, vol}, {h.no2, &d.no2, vol}, {h.o3, &d.o3, vol},
+      {h.ch4, &d.ch4, vol}, {h.co, &d.co, vol}, {h.isop, &d.isop, vol}, {h.acet, &d.acet, vol}, {h.c2h6, &d.c2h6, vol},
+      {h.c3h8, &d.c3h8, vol}, {h.prpe, &d.prpe, vol}, {h.alk4, &d.alk4, vol}, {h.mp, &d.mp, vol}, {h.h2o2, &d.h2o2, vol},
+      {h.cloud, &d.cloud, vol}, {h.qv, &d.qv, vol}, {h.albuv, &d.albuv, plane}, {h.ch2o, &d.ch2o, vol},
+      {h.sza, &d.sza, plane}, {h.default_oh, &d.default_oh, vol}};
+  const size_t nin = sizeof(ins) / sizeof(ins[0]);
+  if (b->d_run1_stage.size() < nin + 3) b->d_run1_stage.resize(nin + 3);
+  for (size_t i = 0; i < nin; ++i) {
+    if (ins[i].host == nullptr) throw OhxError("OHXBoosterRun1: a required field pointer is NULL");
+    b->d_run1_stage[i].ensure(ins[i].n);
+    HIP_CHECK(hipMemcpyAsync(b->d_run1_stage[i].p, ins[i].host, ins[i].n * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    *ins[i].dev = b->d_run1_stage[i].p;
+  }
+  if (h.oh == nullptr) throw OhxError("OHXBoosterRun1: oh is NULL");
+  b->d_run1_stage[nin].ensure(vol);
+  d.oh = b->d_run1_stage[nin].p;
+  d.ndwet = nullptr;
+  if (h.ndwet) {
+    b->d_run1_stage[nin + 1].ensure(vol);
+    d.ndwet = b->d_run1_stage[nin + 1].p;
+  }
+  d.oh_boost = nullptr;
+  if (h.oh_boost) {
+    b->d_run1_stage[nin + 2].ensure(vol);
+    d.oh_boost = b->d_run1_stage[nin + 2].p;
+  }
+  run1_device(*b, d, nullptr);
+  HIP_CHECK(hipMemcpy(h.oh, d.oh, vol * sizeof(float), hipMemcpyDeviceToHost));
+  if (h.ndwet) HIP_CHECK(hipMemcpy(h.ndwet, d.ndwet, vol * sizeof(float), hipMemcpyDeviceToHost));
+  if (h.oh_boost) HIP_CHECK(hipMemcpy(h.oh_boost, d.oh_boost, vol * sizeof(float), hipMemcpyDeviceToHost));
   raise_flag_errors(*b, nullptr);
   API_END();
 }

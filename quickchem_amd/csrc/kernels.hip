@@ -460,6 +460,103 @@ __global__ __launch_bounds__(kBlock) void scan_dense_kernel(const float* __restr
   if (any_inf && !is_inf(missing)) atomicOr(flags, kFlagInfInput);
 }
 
+// ------------------------------------------------------------------ OH Run1: before and after the predict
+
+// One wave = 64 consecutive columns; the three layer fields that need SUM(x(k:km)) sit in LDS
+// [k][lane] so the O(km^2) "each sum from zero, ascending" of the reference
+// (OH_GridCompMod.F90:1468-1478) is bit-faithful and still cheap.
+__global__ __launch_bounds__(kWave) void feature_prep_kernel(PrepArgs a) {
+#pragma clang fp contract(off)
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t col = (uint64_t)blockIdx.x * kWave + lane;
+  const bool valid = col < plane;
+  const uint64_t c = valid ? col : plane - 1;
+  float* lw = lds + lane;
+  float* li = lw + (size_t)a.km * kWave;
+  float* la = li + (size_t)a.km * kWave;
+  float sw = 0.0f, si = 0.0f, sa = 0.0f;
+  for (int k = 0; k < a.km; ++k) {
+    const uint64_t m = c + plane * (uint64_t)k;
+    const float w = a.tauclw[m], ice = a.taucli[m];
+    const float thick = a.zle_bst[m] - a.zle_bst[m + plane];                 // ZLE(k-1) - ZLE(k), :1451
+    float sc = a.sca[0][m] + a.sca[1][m];                                     // BC + OC + BR + DU + SU + SS + NI, :1456-1457
+    sc = sc + a.sca[2][m];
+    sc = sc + a.sca[3][m];
+    sc = sc + a.sca[4][m];
+    sc = sc + a.sca[5][m];
+    sc = sc + a.sca[6][m];
+    const float aod = thick * sc;
+    lw[(size_t)k * kWave] = w;
+    li[(size_t)k * kWave] = ice;
+    la[(size_t)k * kWave] = aod;
+    sw = sw + w;                                                              // SUM(x(1:k)), :1472-1475
+    si = si + ice;
+    sa = sa + aod;
+    if (valid) {
+      a.tauclwup[m] = sw;
+      a.taucliup[m] = si;
+      a.aodup[m] = sa;
+      a.pl_bst[m] = (a.ple_bst[m] + a.ple_bst[m + plane]) * 0.5f;            // :1488
+    }
+  }
+  for (int k = 0; k < a.km; ++k) {                                            // SUM(x(k:km)), :1470-1471,1476
+    float dw = 0.0f, di = 0.0f, da = 0.0f;
+    for (int kk = k; kk < a.km; ++kk) {
+      dw = dw + lw[(size_t)kk * kWave];
+      di = di + li[(size_t)kk * kWave];
+      da = da + la[(size_t)kk * kWave];
+    }
+    if (valid) {
+      const uint64_t m = c + plane * (uint64_t)k;
+      a.tauclwdn[m] = dw;
+      a.tauclidn[m] = di;
+      a.aoddn[m] = da;
+    }
+  }
+  if (valid) a.strato3[col] = a.gmito3[col] - a.gmitto3[col];                 // :1446
+}
+
+// ksubcount = max over columns of COUNT(pl > tropp | tropp_min) (:275-298)
+__global__ __launch_bounds__(kBlock) void k_slab_kernel(SlabArgs a) {
+#pragma clang fp contract(off)
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  int best = 0, bad = 0;
+  for (uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; col < plane; col += stride) {
+    const float tp = a.tropp[col];
+    const float lim = a.dynamic_k_range ? tp : a.tropp_min;
+    bad += (tp <= a.tropp_min) ? 1 : 0;
+    int cnt = 0;
+    for (int k = 0; k < a.km; ++k) {
+      const float pl = (a.ple_mod[col + plane * (uint64_t)k] + a.ple_mod[col + plane * (uint64_t)(k + 1)]) * 0.5f;
+      cnt += (pl > lim) ? 1 : 0;
+    }
+    best = cnt > best ? cnt : best;
+  }
+  atomicMax(&a.result[0], best);
+  if (bad) atomicAdd(&a.result[1], bad);
+}
+
+// tropopause mask and mol/mol -> molec/cm3 (:1247-1257, 1579-1595)
+__global__ __launch_bounds__(kBlock) void post_process_kernel(PostArgs a) {
+#pragma clang fp contract(off)
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t total = plane * (uint64_t)a.km;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += stride) {
+    const uint64_t col = m % plane;
+    const float pl = (a.ple_mod[m] + a.ple_mod[m + plane]) * 0.5f;
+    const float q = a.q_mod[m];
+    const float tv = a.t_mod[m] * (1.0f + q / a.epsilon) / (1.0f + q);
+    const float ndwet = (a.avogad * pl) / (a.runiv * tv);
+    const float ohv = (pl > a.tropp[col]) ? a.oh_ml[m] : a.default_oh[m];
+    a.oh[m] = (ohv * ndwet) * 1.0e-6f;
+    if (a.ndwet) a.ndwet[m] = ndwet;
+  }
+}
+
 // ------------------------------------------------------------------ synthetic inputs
 
 __global__ __launch_bounds__(kBlock) void synth_rows_kernel(uint32_t seed, int im, int jm, int km, uint64_t row_begin,
@@ -665,6 +762,31 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
     default: OHX_LAUNCH_FIELDS(2, 2);
   }
 #undef OHX_LAUNCH_FIELDS
+}
+
+hipError_t launch_feature_prep(const PrepArgs& a, hipStream_t stream) {
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  if (plane == 0 || a.km <= 0) return hipSuccess;
+  const size_t lds = (size_t)3 * a.km * kWave * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipError_t e = ensure_lds(feature_prep_kernel, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(feature_prep_kernel, dim3((unsigned)((plane + kWave - 1) / kWave)), dim3(kWave), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_k_slab(const SlabArgs& a, hipStream_t stream) {
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  if (plane == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_slab_kernel, dim3(grid_for(plane, 256, 8)), dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_post_process(const PostArgs& a, hipStream_t stream) {
+  const uint64_t total = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)a.km;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(post_process_kernel, dim3(grid_for(total, 256, 16)), dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream) {

@@ -72,6 +72,36 @@ struct FieldsArgs {
   uint64_t tile_begin = 0, tile_end = 0;   // 64-row tiles of this launch
 };
 
+// OH Run1's feature engineering and post-processing (include/ohxgb.h part 3), device pointers.
+struct PrepArgs {
+  int im = 0, jm = 0, km = 0;
+  const float *ple_bst = nullptr, *zle_bst = nullptr, *tauclw = nullptr, *taucli = nullptr;
+  const float* sca[7] = {};
+  const float *gmito3 = nullptr, *gmitto3 = nullptr;
+  float *pl_bst = nullptr, *tauclwdn = nullptr, *tauclidn = nullptr, *taucliup = nullptr, *tauclwup = nullptr;
+  float *aodup = nullptr, *aoddn = nullptr, *strato3 = nullptr;
+};
+
+struct SlabArgs {
+  int im = 0, jm = 0, km = 0;
+  int dynamic_k_range = 1;
+  float tropp_min = 4000.0f;
+  const float *ple_mod = nullptr, *tropp = nullptr;
+  int32_t* result = nullptr;   // [0] = ksubcount (max over columns), [1] = COUNT(tropp <= tropp_min)
+};
+
+struct PostArgs {
+  int im = 0, jm = 0, km = 0;
+  float avogad = 0, runiv = 0, epsilon = 0;
+  const float *ple_mod = nullptr, *t_mod = nullptr, *q_mod = nullptr, *tropp = nullptr;
+  const float *default_oh = nullptr, *oh_ml = nullptr;
+  float *oh = nullptr, *ndwet = nullptr;
+};
+
+hipError_t launch_feature_prep(const PrepArgs& a, hipStream_t stream);
+hipError_t launch_k_slab(const SlabArgs& a, hipStream_t stream);
+hipError_t launch_post_process(const PostArgs& a, hipStream_t stream);
+
 enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super4 };
 
 const char* kernel_kind_name(KernelKind k);

@@ -13,7 +13,7 @@ from tests import helpers
 def header_symbols():
     text = open(os.path.join(helpers.ROOT, "include", "ohxgb.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:XG|OHX)[A-Za-z]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:XG|OHX)[A-Za-z0-9]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
