@@ -50,9 +50,12 @@ def parse_args():
     ap.add_argument("--missing-ppm", type=int, default=0, help="inject -999.0/NaN at this rate per million entries")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--shuffle", action="store_true", help="permute the rows (destroys spatial coherence)")
-    ap.add_argument("--path", default="rows", choices=["rows", "fields"],
+    ap.add_argument("--gather-chunks", type=int, default=4,
+                    help="N > 1: cut the shard into this many pieces so that a piece's all-gather overlaps the next "
+                         "piece's prediction (1 = predict everything, then one all-gather)")
+    ap.add_argument("--path", default="rows", choices=["rows", "fields", "run1"],
                     help="rows: AoS xx_carr -> margins (the headline); fields: the fused SoA call, 27 MAPL fields -> "
-                         "10**pred*OHscale (1 GPU only)")
+                         "10**pred*OHscale; run1: OHXBoosterRun1Device, imports -> INTERNAL OH (both 1 GPU only)")
     return ap.parse_args()
 
 
@@ -82,6 +85,73 @@ def cpu_baseline(model_image, rows_dev, budget_s):
     return {"value": n / t, "unit": "gridcells/s", "cores": cores, "kind": "port",
             "sample": f"first {n} rows of the batch, oracle/xgb_oracle.c (OpenMP, {cores} threads), "
                       f"XGDMatrixCreateFromMat + XGBoosterPredict, {t:.2f} s"}, out, n
+
+
+def bench_run1(args, grid, n_total, model, booster, dev, t_model):
+    """OH Run1 from the imports to INTERNAL OH, everything resident in HBM."""
+    import ctypes as C
+    from quickchem_amd import capi, synth
+    im, jm, km = grid
+    plane, vol, edge = im * jm, im * jm * km, im * jm * (km + 1)
+    g = torch.Generator(device=dev).manual_seed(23)
+
+    def u(n, lo, hi):
+        return (lo + (hi - lo) * torch.rand(n, device=dev, generator=g, dtype=torch.float32)).contiguous()
+    keep = {}
+    a = capi.OHXRun1Args()
+    a.im, a.jm, a.km = im, jm, km
+    a.dynamic_k_range, a.tropp_min, a.ohscale, a.missing = 1, 4000.0, 0.85, synth.XX_MISS
+    a.avogad, a.runiv, a.epsilon = 6.023e26, 8314.47, 18.015 / 28.965
+    sig = (torch.arange(km + 1, device=dev, dtype=torch.float32) / km) ** 2
+    ps = u(plane, 6.0e4, 1.04e5)
+    keep["ple_mod"] = (1.0 + (ps[None, :] - 1.0) * sig[:, None]).contiguous().reshape(-1)        # (im,jm,0:km) Fortran order
+    keep["ple_bst"] = keep["ple_mod"].clone()
+    keep["zle_bst"] = (8.0e4 * (1.0 - sig[:, None]) * u(plane, 0.9, 1.1)[None, :]).contiguous().reshape(-1)
+    for name, lo, hi, n in (("t_mod", 190, 310, vol), ("q_mod", 1e-7, 2e-2, vol), ("tropp_mod", 9e3, 3e4, plane),
+                            ("tauclw", 0, 4, vol), ("taucli", 0, 2, vol), ("gmito3", 250, 450, plane),
+                            ("gmitto3", 20, 60, plane), ("lat_deg", -90, 90, plane), ("albuv", 0.02, 0.9, plane),
+                            ("sza", 0, 113, plane), ("default_oh", 1e-15, 5e-13, vol)):
+        keep[name] = u(n, lo, hi)
+    # the features that are used as they are come from the seeded generator (spatially coherent)
+    direct = {"t_bst": 2, "no2": 3, "o3": 4, "ch4": 5, "co": 6, "isop": 7, "acet": 8, "c2h6": 9, "c3h8": 10, "prpe": 11,
+              "alk4": 12, "mp": 13, "h2o2": 14, "cloud": 19, "qv": 20, "ch2o": 25}
+    for name, f in direct.items():
+        t = torch.empty(vol, dtype=torch.float32, device=dev)
+        synth.field_device(grid, f, t)
+        keep[name] = t
+    sca = [u(vol, 0, 5e-6) for _ in range(7)]
+    a.scacoef = (C.c_void_p * 7)(*[t.data_ptr() for t in sca])
+    for name, t in keep.items():
+        setattr(a, name, t.data_ptr())
+    oh = torch.empty(vol, dtype=torch.float32, device=dev)
+    boost = torch.empty(vol, dtype=torch.float32, device=dev)
+    k1, k2 = C.c_int32(), C.c_int32()
+    a.oh, a.oh_boost, a.ndwet = oh.data_ptr(), boost.data_ptr(), None
+    a.k1, a.k2 = C.cast(C.pointer(k1), C.c_void_p), C.cast(C.pointer(k2), C.c_void_p)
+    lib = booster.lib
+    stream = torch.cuda.current_stream()
+
+    def step():
+        capi.check(lib, lib.OHXBoosterRun1Device(booster.handle, C.byref(a), stream.cuda_stream))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    per_step = (time.perf_counter() - t0) / args.steps
+    booster.check()
+    nslab = plane * (k2.value - k1.value + 1)
+    print(json.dumps({
+        "metric": "OH gridcells/sec (XGBoost predict), C360 L72 batch", "value": nslab / per_step,
+        "unit": "gridcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.grid} L{km}: OH Run1 imports -> INTERNAL OH in HBM (feature engineering, "
+                               f"k-slab {k1.value}..{k2.value}, predict, tropopause mask, unit conversion)",
+                   "grid": list(grid), "rows_predicted": nslab, "kernel": args.kernel, "params": args.param},
+        "roofline": None, "cpu_baseline": None}), flush=True)
 
 
 def measured_traffic(grid_name, kernel, model_nodes):
@@ -191,10 +261,11 @@ def main():
         booster.set_param(name, val)
     t_model = time.perf_counter() - t0
 
-    if args.path == "fields":
+    if args.path in ("fields", "run1"):
         if world != 1:
-            raise SystemExit("--path fields is a single-GPU measurement")
-        return bench_fields(args, grid, n_total, model, booster, dev, t_model)
+            raise SystemExit(f"--path {args.path} is a single-GPU measurement")
+        fn = bench_fields if args.path == "fields" else bench_run1
+        return fn(args, grid, n_total, model, booster, dev, t_model)
 
     # ---- the batch: this rank's contiguous row shard, generated in HBM ----
     rows = torch.empty((n_local, synth.NFEAT), dtype=torch.float32, device=dev)
@@ -206,10 +277,13 @@ def main():
         rows = rows[perm].contiguous()
         del perm
     torch.cuda.synchronize()
-    dmat = capi.DMatrix(device_ptr=rows.data_ptr(), nrow=n_local, ncol=synth.NFEAT, missing=synth.XX_MISS)
     out_local = torch.empty(n_local, dtype=torch.float32, device=dev)
     even = (n_total % world == 0)
+    # pieces of the shard: one DMatrix view each (device pointers into `rows`)
     gather = world > 1 or force_dist
+    pieces = shard.chunk_bounds(n_local, args.gather_chunks if (gather and even) else 1, 64 * 256 * 20 * 2)
+    dmats = [capi.DMatrix(device_ptr=rows.data_ptr() + lo * synth.NFEAT * 4, nrow=hi - lo, ncol=synth.NFEAT,
+                          missing=synth.XX_MISS) for lo, hi in pieces]
     out_full = torch.empty(n_total, dtype=torch.float32, device=dev) if gather else out_local
     stream = torch.cuda.current_stream()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -218,11 +292,17 @@ def main():
     def step(i=None):
         if i is not None:
             ev0[i].record(stream)
-        booster.predict_device(dmat, out_local.data_ptr(), stream=stream.cuda_stream)
+        works = []
+        for (lo, hi), dm in zip(pieces, dmats):
+            booster.predict_device(dm, out_local.data_ptr() + lo * 4, stream=stream.cuda_stream)
+            if gather and len(pieces) > 1:
+                works.append(shard.all_gather_chunk_async(out_full, out_local, lo, hi, n_local, world))
         if i is not None:
-            ev1[i].record(stream)
-        if gather:
+            ev1[i].record(stream)      # with N > 1 this spans the predict launches of all pieces
+        if gather and len(pieces) == 1:
             shard.all_gather_rows(out_full, out_local, n_total, world, even)
+        for w in works:
+            w.wait()
 
     def fence():
         torch.cuda.synchronize()
@@ -251,8 +331,7 @@ def main():
         kernel_s = float(t.item())
 
     info = booster.info()
-    tiles = (n_local + 63) // 64
-    launches_per_step = -(-tiles // (256 * 20 * 2))  # one launch per two residencies of 256 CUs x 20 waves
+    launches_per_step = sum(-(-((hi - lo + 63) // 64) // (256 * 20 * 2)) for lo, hi in pieces)  # per 2 residencies
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total / (elapsed / args.steps)
     algo_bytes = BYTES_PER_CELL * n_local + info["node_bytes"]
@@ -286,7 +365,7 @@ def main():
                           "mean_path": round(model.mean_path, 3), "seed": synth.MODEL_SEED,
                           "build_s": round(t_model, 2)},
                 "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle),
-                "parallelism": f"rows{world}",
+                "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -35,3 +35,26 @@ def all_gather_rows(out_full: torch.Tensor, out_local: torch.Tensor, n_total: in
     for r in range(world):
         row0, n = row_shard(n_total, world, r)
         out_full[row0:row0 + n] = slots[r * slot: r * slot + n]
+
+
+def chunk_bounds(n_local: int, nchunks: int, granule: int) -> list:
+    """Cut [0, n_local) into at most `nchunks` pieces whose sizes are multiples of `granule`
+    (the rows one launch covers), so that a piece's all-gather can overlap the next piece's
+    prediction without leaving ragged launches behind."""
+    if nchunks <= 1 or n_local <= granule:
+        return [(0, n_local)]
+    per = -(-n_local // nchunks)
+    per = -(-per // granule) * granule
+    out, lo = [], 0
+    while lo < n_local:
+        hi = min(n_local, lo + per)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def all_gather_chunk_async(out_full: torch.Tensor, out_local: torch.Tensor, lo: int, hi: int, n_local: int, world: int):
+    """Start gathering rows [lo, hi) of every rank's (equal-sized) shard straight into their
+    final places in `out_full`; returns the work handle (wait() before reading out_full)."""
+    views = [out_full[r * n_local + lo: r * n_local + hi] for r in range(world)]
+    return dist.all_gather(views, out_local[lo:hi], async_op=True)

@@ -27,6 +27,15 @@ def test_row_shards_tile_the_batch():
     assert shard.row_shard(55_987_200, 8, 3) == (3 * 6_998_400, 6_998_400)
 
 
+def test_chunk_bounds_cover_the_shard():
+    for n_local in (1, 639, 640, 641, 6_998_400, 53_265_600):
+        for k in (1, 2, 4, 7):
+            b = shard.chunk_bounds(n_local, k, 655_360)
+            assert b[0][0] == 0 and b[-1][1] == n_local and len(b) <= max(k, 1)
+            assert all(hi > lo for lo, hi in b) and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+            assert all((hi - lo) % 655_360 == 0 for lo, hi in b[:-1])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -48,6 +57,14 @@ def _worker(rank, world, port, n_total, image_path, out_dir):
         full = torch.empty(n_total, dtype=torch.float32)
         shard.all_gather_rows(full, local, n_total, world, n_total % world == 0)
         np.save(os.path.join(out_dir, f"rank{rank}.npy"), full.numpy())
+        if n_total % world == 0:
+            # the overlapped form bench.py uses: pieces gathered asynchronously into their final places
+            full2 = torch.zeros(n_total, dtype=torch.float32)
+            works = [shard.all_gather_chunk_async(full2, local, lo, hi, n, world)
+                     for lo, hi in shard.chunk_bounds(n, 3, 640)]
+            for w in works:
+                w.wait()
+            assert torch.equal(full2.view(torch.int32), full.view(torch.int32))
     finally:
         dist.destroy_process_group()
 
