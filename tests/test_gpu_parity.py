@@ -277,3 +277,14 @@ def test_reference_binding_module_drives_the_gpu(torch_cuda, tmp_path, small_mod
     pred = np.frombuffer(raw, dtype="<f4", count=n, offset=8)
     want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
     assert np.array_equal(helpers.bits(pred), helpers.bits(want))
+
+
+def test_oversized_trees_use_the_packed_fallback(torch_cuda):
+    """Two trees of ~1e6 nodes each: too many groups for the super-node format."""
+    big = synth.make_model(num_trees=2, max_depth=24, sample_log2=20, min_leaf=1, grid=synth.GRIDS["C48"])
+    rows = with_missing(synth.rows_cpu(synth.GRIDS["C48"], 100000, 30000), 0.002)
+    want = helpers.oracle_predict(big.image, rows, synth.XX_MISS)
+    b = capi.Booster(model_buffer=big.image)
+    d = capi.DMatrix(rows, missing=synth.XX_MISS)
+    assert np.array_equal(helpers.bits(b.predict(d)), helpers.bits(want))
+    assert b.info()["packed"] == 1

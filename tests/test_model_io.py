@@ -120,3 +120,14 @@ def test_layout_parameters_change_slots_not_nodes(deep_model):
     assert b.info()["packed"] == 0 and b.info()["node_bytes"] == 16 * bfs["num_slots"]
     with pytest.raises(capi.OhxError):
         b.set_param("ohx_kernel", "nope")
+
+
+def test_format_selection_falls_back_when_a_tree_is_too_big_for_super_nodes():
+    """The super-node format addresses at most 16 384 grandchild groups per tree; a bigger tree makes
+    the booster fall back to the packed 8-byte format (host logic, no GPU needed to see it)."""
+    big = synth.make_model(num_trees=2, max_depth=24, sample_log2=20, min_leaf=1, grid=synth.GRIDS["C48"])
+    b = capi.Booster(model_buffer=big.image)
+    info = b.info()
+    assert big.num_nodes > 3 * 65536 and info["packed"] == 1, (big.num_nodes, info)
+    small = synth.make_model(num_trees=2, max_depth=8, sample_log2=14, min_leaf=4, grid=synth.GRIDS["C12"])
+    assert capi.Booster(model_buffer=small.image).info()["packed"] == 2
