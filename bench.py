@@ -248,6 +248,7 @@ def main():
     row0, n_local = shard.row_shard(n_total, world, rank)
 
     # ---- the booster: seeded synthetic OH model, identical on every rank ----
+    synth.set_threads(max(1, (os.cpu_count() or 8) // max(world, 1)))
     t0 = time.perf_counter()
     model = synth.make_model(num_trees=args.trees, max_depth=args.depth, sample_log2=args.sample_log2)
     booster = capi.Booster(model_buffer=model.image)

@@ -9,6 +9,9 @@
 // input comes from here.  Nothing in this file predicts anything.
 #include <algorithm>
 #include <cmath>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +48,16 @@ inline void cell_of(uint64_t m, int im, int jm, int* i, int* j, int* k) {
 extern "C" {
 
 const char* ohx_synth_last_error(void) { return g_err.c_str(); }
+
+// torch.distributed.run exports OMP_NUM_THREADS=1 to every rank; the generators are told their
+// share of the host cores explicitly instead.
+void ohx_synth_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 // rows [nrows][27], PL in hPa (as xx_carr holds it, OH_GridCompMod.F90:314)
 int ohx_synth_rows_cpu(uint32_t seed, int im, int jm, int km, uint64_t row_begin, uint64_t nrows, float* out) {

@@ -56,10 +56,16 @@ def _load():
                                         C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.ohx_synth_free.argtypes = [C.c_void_p]
+        lib.ohx_synth_set_threads.argtypes = [C.c_int]
         lib.ohx_model_convert.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_uint64)]
         _lib = lib
     return _lib
+
+
+def set_threads(n: int) -> None:
+    """Host threads the generators may use (torchrun pins OMP_NUM_THREADS=1 per rank)."""
+    _load().ohx_synth_set_threads(int(n))
 
 
 def _check(rc: int) -> None:
