@@ -211,8 +211,8 @@ def bench_fields(args, grid, n_total, model, booster, dev, t_model):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.grid} L{km}: fused SoA call, 27 MAPL fields in HBM -> 10**pred * OHscale",
                    "grid": list(grid), "rows_total": n_total, "kernel": args.kernel, "params": args.param,
-                   "model": {"trees": info["num_trees"], "nodes": info["num_nodes"], "node_bytes": info["node_bytes"],
-                             "build_s": round(t_model, 2)}},
+                   "booster": {"trees": info["num_trees"], "nodes": info["num_nodes"], "node_bytes": info["node_bytes"],
+                               "build_s": round(t_model, 2)}},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "predict_fields_kernel<2,2>",
                      "kernel_ms": per_step * 1e3, "algorithmic_bytes": algo},
@@ -361,7 +361,7 @@ def main():
                 "workload": f"{args.grid} L{grid[2]}: {n_total} gridcells x 27 float32 features (AoS rows in HBM), "
                             f"{world} contiguous row shard(s)" + (", all-gather of the OH field" if world > 1 else ""),
                 "grid": list(grid), "rows_total": n_total, "rows_per_gpu": n_local,
-                "model": {"trees": info["num_trees"], "max_depth": info["max_depth"], "nodes": info["num_nodes"],
+                "booster": {"trees": info["num_trees"], "max_depth": info["max_depth"], "nodes": info["num_nodes"],
                           "node_slots": info["num_slots"], "node_bytes": info["node_bytes"],
                           "mean_path": round(model.mean_path, 3), "seed": synth.MODEL_SEED,
                           "build_s": round(t_model, 2)},

@@ -163,7 +163,7 @@ struct BoosterObj {
   std::vector<DevBuf<float>> d_stage;  // fused host path: per-field staging
   DevBuf<float> d_stage_out, d_stage_margin;
   // Run1: engineered features, OH_ML and the slab result stay in HBM between the steps
-  DevBuf<float> d_run1[9];
+  DevBuf<float> d_run1[10];
   DevBuf<int32_t> d_slab;
   std::vector<DevBuf<float>> d_run1_stage;
 };
@@ -718,6 +718,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   const size_t plane = (size_t)r.im * (size_t)r.jm, vol = plane * (size_t)r.km;
   for (int i = 0; i < 8; ++i) b.d_run1[i].ensure(i == 7 ? plane : vol);
   b.d_run1[8].ensure(vol);
+  b.d_run1[9].ensure(vol);
   b.d_slab.ensure(2);
   float* pl_bst = b.d_run1[0].p;
   float *tauclwdn = b.d_run1[1].p, *tauclidn = b.d_run1[2].p, *taucliup = b.d_run1[3].p, *tauclwup = b.d_run1[4].p;
@@ -731,7 +732,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   pa.gmito3 = r.gmito3; pa.gmitto3 = r.gmitto3;
   pa.pl_bst = pl_bst; pa.tauclwdn = tauclwdn; pa.tauclidn = tauclidn; pa.taucliup = taucliup; pa.tauclwup = tauclwup;
   pa.aodup = aodup; pa.aoddn = aoddn; pa.strato3 = strato3;
-  HIP_CHECK(launch_feature_prep(pa, stream));
+  HIP_CHECK(launch_feature_prep(pa, b.d_run1[9].p, stream));
 
   SlabArgs sa;
   sa.im = r.im; sa.jm = r.jm; sa.km = r.km;

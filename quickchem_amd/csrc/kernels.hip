@@ -462,60 +462,58 @@ __global__ __launch_bounds__(kBlock) void scan_dense_kernel(const float* __restr
 
 // ------------------------------------------------------------------ OH Run1: before and after the predict
 
-// One wave = 64 consecutive columns; the three layer fields that need SUM(x(k:km)) sit in LDS
-// [k][lane] so the O(km^2) "each sum from zero, ascending" of the reference
-// (OH_GridCompMod.F90:1468-1478) is bit-faithful and still cheap.
-__global__ __launch_bounds__(kWave) void feature_prep_kernel(PrepArgs a) {
+// Feature engineering in two kernels.  (1) pointwise, one thread per gridcell: PL_BST, the
+// layer AOD, stratO3 - plain coalesced streams.  (2) column sums, one wave per 64 consecutive
+// columns and per layer field: the column goes through LDS [k][lane] once, SUM(x(1:k)) is the
+// running sum of that pass, and every SUM(x(k:km)) is then accumulated FROM ZERO in ascending
+// level order (O(km^2) LDS reads), which is how the reference's SUM intrinsic rounds
+// (OH_GridCompMod.F90:1468-1478); a suffix scan from the bottom would round differently.
+__global__ __launch_bounds__(kBlock) void feature_pointwise_kernel(PrepArgs a, float* __restrict__ aod) {
 #pragma clang fp contract(off)
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x;
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
-  const uint64_t col = (uint64_t)blockIdx.x * kWave + lane;
-  const bool valid = col < plane;
-  const uint64_t c = valid ? col : plane - 1;
-  float* lw = lds + lane;
-  float* li = lw + (size_t)a.km * kWave;
-  float* la = li + (size_t)a.km * kWave;
-  float sw = 0.0f, si = 0.0f, sa = 0.0f;
-  for (int k = 0; k < a.km; ++k) {
-    const uint64_t m = c + plane * (uint64_t)k;
-    const float w = a.tauclw[m], ice = a.taucli[m];
-    const float thick = a.zle_bst[m] - a.zle_bst[m + plane];                 // ZLE(k-1) - ZLE(k), :1451
-    float sc = a.sca[0][m] + a.sca[1][m];                                     // BC + OC + BR + DU + SU + SS + NI, :1456-1457
+  const uint64_t total = plane * (uint64_t)a.km;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += stride) {
+    a.pl_bst[m] = (a.ple_bst[m] + a.ple_bst[m + plane]) * 0.5f;               // :1488
+    const float thick = a.zle_bst[m] - a.zle_bst[m + plane];                  // ZLE(k-1) - ZLE(k), :1451
+    float sc = a.sca[0][m] + a.sca[1][m];                                      // BC+OC+BR+DU+SU+SS+NI, :1456-1457
     sc = sc + a.sca[2][m];
     sc = sc + a.sca[3][m];
     sc = sc + a.sca[4][m];
     sc = sc + a.sca[5][m];
     sc = sc + a.sca[6][m];
-    const float aod = thick * sc;
-    lw[(size_t)k * kWave] = w;
-    li[(size_t)k * kWave] = ice;
-    la[(size_t)k * kWave] = aod;
-    sw = sw + w;                                                              // SUM(x(1:k)), :1472-1475
-    si = si + ice;
-    sa = sa + aod;
-    if (valid) {
-      a.tauclwup[m] = sw;
-      a.taucliup[m] = si;
-      a.aodup[m] = sa;
-      a.pl_bst[m] = (a.ple_bst[m] + a.ple_bst[m + plane]) * 0.5f;            // :1488
-    }
+    aod[m] = thick * sc;
+    if (m < plane) a.strato3[m] = a.gmito3[m] - a.gmitto3[m];                  // :1446
   }
-  for (int k = 0; k < a.km; ++k) {                                            // SUM(x(k:km)), :1470-1471,1476
-    float dw = 0.0f, di = 0.0f, da = 0.0f;
-    for (int kk = k; kk < a.km; ++kk) {
-      dw = dw + lw[(size_t)kk * kWave];
-      di = di + li[(size_t)kk * kWave];
-      da = da + la[(size_t)kk * kWave];
-    }
-    if (valid) {
-      const uint64_t m = c + plane * (uint64_t)k;
-      a.tauclwdn[m] = dw;
-      a.tauclidn[m] = di;
-      a.aoddn[m] = da;
-    }
+}
+
+// blockIdx.y selects the field: 0 TAUCLW, 1 TAUCLI, 2 aod
+__global__ __launch_bounds__(kBlock) void feature_column_sums_kernel(PrepArgs a, const float* __restrict__ aod) {
+#pragma clang fp contract(off)
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t col = ((uint64_t)blockIdx.x * kWavesPerBlock + wave) * kWave + lane;
+  const bool valid = col < plane;
+  const uint64_t c = valid ? col : plane - 1;
+  const float* src = blockIdx.y == 0 ? a.tauclw : (blockIdx.y == 1 ? a.taucli : aod);
+  float* up = blockIdx.y == 0 ? a.tauclwup : (blockIdx.y == 1 ? a.taucliup : a.aodup);
+  float* dn = blockIdx.y == 0 ? a.tauclwdn : (blockIdx.y == 1 ? a.tauclidn : a.aoddn);
+  float* col_lds = lds + (size_t)wave * a.km * kWave + lane;
+  // the column comes in with independent loads (eight in flight per lane), the sums run from LDS
+#pragma unroll 8
+  for (int k = 0; k < a.km; ++k) col_lds[(size_t)k * kWave] = __builtin_nontemporal_load(src + c + plane * (uint64_t)k);
+  float run = 0.0f;
+  for (int k = 0; k < a.km; ++k) {
+    run = run + col_lds[(size_t)k * kWave];                                    // SUM(x(1:k))
+    if (valid) __builtin_nontemporal_store(run, up + c + plane * (uint64_t)k);
   }
-  if (valid) a.strato3[col] = a.gmito3[col] - a.gmitto3[col];                 // :1446
+  for (int k = 0; k < a.km; ++k) {                                             // SUM(x(k:km)), from zero
+    float s = 0.0f;
+    for (int kk = k; kk < a.km; ++kk) s = s + col_lds[(size_t)kk * kWave];
+    if (valid) __builtin_nontemporal_store(s, dn + c + plane * (uint64_t)k);
+  }
 }
 
 // ksubcount = max over columns of COUNT(pl > tropp | tropp_min) (:275-298)
@@ -764,14 +762,18 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
 #undef OHX_LAUNCH_FIELDS
 }
 
-hipError_t launch_feature_prep(const PrepArgs& a, hipStream_t stream) {
+hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_t stream) {
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
   if (plane == 0 || a.km <= 0) return hipSuccess;
-  const size_t lds = (size_t)3 * a.km * kWave * sizeof(float);
+  hipLaunchKernelGGL(feature_pointwise_kernel, dim3(grid_for(plane * (uint64_t)a.km, 256, 16)), dim3(kBlock), 0, stream,
+                     a, aod_scratch);
+  const size_t lds = (size_t)kWavesPerBlock * a.km * kWave * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t e = ensure_lds(feature_prep_kernel, lds);
+  hipError_t e = ensure_lds(feature_column_sums_kernel, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(feature_prep_kernel, dim3((unsigned)((plane + kWave - 1) / kWave)), dim3(kWave), lds, stream, a);
+  const uint64_t cols_per_block = (uint64_t)kWavesPerBlock * kWave;
+  hipLaunchKernelGGL(feature_column_sums_kernel, dim3((unsigned)((plane + cols_per_block - 1) / cols_per_block), 3),
+                     dim3(kBlock), lds, stream, a, (const float*)aod_scratch);
   return hipGetLastError();
 }
 

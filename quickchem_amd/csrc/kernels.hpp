@@ -98,7 +98,7 @@ struct PostArgs {
   float *oh = nullptr, *ndwet = nullptr;
 };
 
-hipError_t launch_feature_prep(const PrepArgs& a, hipStream_t stream);
+hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_t stream);  // aod_scratch: (im,jm,km)
 hipError_t launch_k_slab(const SlabArgs& a, hipStream_t stream);
 hipError_t launch_post_process(const PostArgs& a, hipStream_t stream);
 
