@@ -71,7 +71,7 @@ int XGBoosterCreate(const DMatrixHandle dmats[], bst_ulong len, BoosterHandle* o
 int XGBoosterFree(BoosterHandle handle);
 
 /* Shared/xgb_fortran_api.F90:19-23, called at OH_GridCompMod.F90:261.  Format
- * by extension as in xgboost 1.6.0: ".json" JSON, ".ubj" UBJSON (refused),
+ * by extension as in xgboost 1.6.0: ".json" JSON, ".ubj" UBJSON (draft 12),
  * anything else the legacy binary format of the production ".model"/".bin"
  * files (OH_GridComp/OH_instance_OH.rc:17-20). */
 int XGBoosterLoadModel(BoosterHandle handle, const char* fname);

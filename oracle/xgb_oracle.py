@@ -129,8 +129,82 @@ def load_json(text) -> OracleModel:
     return model
 
 
+def _ubj_value(buf: bytes, off: int, t: int):
+    """One UBJSON (draft 12) value of type marker `t` starting at `off`; returns (value, new offset)."""
+    ints = {ord("i"): ">b", ord("U"): ">B", ord("I"): ">h", ord("l"): ">i", ord("L"): ">q"}
+    if t in ints:
+        fmt = ints[t]
+        return struct.unpack_from(fmt, buf, off)[0], off + struct.calcsize(fmt)
+    if t == ord("d"):
+        return float(np.frombuffer(buf, dtype=">f4", count=1, offset=off)[0]), off + 4
+    if t == ord("D"):
+        return struct.unpack_from(">d", buf, off)[0], off + 8
+    if t in (ord("T"), ord("F"), ord("Z")):
+        return {ord("T"): True, ord("F"): False, ord("Z"): None}[t], off
+    if t == ord("C"):
+        return chr(buf[off]), off + 1
+    if t in (ord("S"), ord("H")):
+        n, off = _ubj_value(buf, off + 1, buf[off])
+        return buf[off:off + n].decode(), off + n
+    if t in (ord("["), ord("{")):
+        elem, count = None, None
+        if buf[off] == ord("$"):
+            elem = buf[off + 1]
+            off += 2
+        if buf[off] == ord("#"):
+            count, off = _ubj_value(buf, off + 2, buf[off + 1])
+        if t == ord("["):
+            if elem is not None and elem in (ord("d"), ord("l"), ord("U"), ord("L"), ord("i"), ord("I"), ord("D")):
+                dt = {ord("d"): ">f4", ord("l"): ">i4", ord("U"): "u1", ord("L"): ">i8", ord("i"): "i1", ord("I"): ">i2",
+                      ord("D"): ">f8"}[elem]
+                arr = np.frombuffer(buf, dtype=dt, count=count, offset=off)
+                return arr, off + arr.nbytes
+            out = []
+            while count is None or len(out) < count:
+                et = elem if elem is not None else buf[off]
+                if elem is None:
+                    off += 1
+                if count is None and et == ord("]"):
+                    break
+                v, off = _ubj_value(buf, off, et)
+                out.append(v)
+            return out, off
+        out = {}
+        while count is None or len(out) < count:
+            kt = buf[off]
+            off += 1
+            if count is None and kt == ord("}"):
+                break
+            n, off = _ubj_value(buf, off, kt)
+            key = buf[off:off + n].decode()
+            off += n
+            vt = elem if elem is not None else buf[off]
+            if elem is None:
+                off += 1
+            out[key], off = _ubj_value(buf, off, vt)
+        return out, off
+    raise ValueError(f"oracle: unknown UBJSON marker {t!r}")
+
+
+def load_ubjson(buf: bytes) -> OracleModel:
+    doc, _ = _ubj_value(buf, 1, buf[0])
+    learner = doc["learner"]
+    lmp, gb = learner["learner_model_param"], learner["gradient_booster"]
+    model = OracleModel(np.float32(float(lmp["base_score"])), int(lmp["num_feature"]), learner["objective"]["name"])
+    for jt in gb["model"]["trees"]:
+        model.trees.append(OracleTree(
+            cleft=np.asarray(jt["left_children"]).astype(np.int32),
+            cright=np.asarray(jt["right_children"]).astype(np.int32),
+            feature=np.asarray(jt["split_indices"]).astype(np.uint32),
+            default_left=np.asarray(jt["default_left"]).astype(bool),
+            value=np.asarray(jt["split_conditions"]).astype(np.float32)))
+    return model
+
+
 def load_model(buf: bytes) -> OracleModel:
-    return load_json(buf) if buf[:1] == b"{" else load_legacy_binary(buf)
+    if buf[:1] == b"{":
+        return load_ubjson(buf) if buf[1:2] in (b"L", b"l", b"I", b"U", b"i", b"$", b"#") else load_json(buf)
+    return load_legacy_binary(buf)
 
 
 # --------------------------------------------------------------------- prediction

@@ -59,16 +59,18 @@ struct Forest {
 
 // ---- file formats ----
 // Dispatch as xgboost 1.6.0's XGBoosterLoadModel does: ".json" => JSON,
-// ".ubj" => UBJSON (rejected here), anything else => legacy binary, where a
-// leading '{' still selects JSON.
+// ".ubj" => UBJSON, anything else => legacy binary, where a leading '{' still
+// selects JSON (or UBJSON, told apart by the byte that follows).
 Forest load_model_file(const std::string& path);
 Forest load_model_buffer(const void* buf, size_t len);
 Forest parse_legacy_binary(const uint8_t* p, size_t len);
 Forest parse_json_model(const char* text, size_t len);
+Forest parse_ubjson_model(const uint8_t* p, size_t len);
 
 void save_model_file(const Forest& f, const std::string& path);
 std::vector<uint8_t> write_legacy_binary(const Forest& f);
 std::string write_json_model(const Forest& f);
+std::vector<uint8_t> write_ubjson_model(const Forest& f);
 
 // Objectives whose prediction transform is the identity (the OH model is
 // reg:squarederror; files written by xgboost < 1.0 call it reg:linear).

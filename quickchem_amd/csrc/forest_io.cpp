@@ -1,4 +1,4 @@
-// Model file reader/writer: XGBoost legacy binary and JSON (schema as of 1.6.0).
+// Model file reader/writer: XGBoost legacy binary, JSON and UBJSON (schema as of 1.6.0).
 //
 // Replaces what libxgboost does behind XGBoosterLoadModel / XGBoosterSaveModel
 // (/root/reference Shared/xgb_fortran_api.F90:19-31).  The production OH models
@@ -372,9 +372,241 @@ void put_array(std::string& out, const char* key, const std::vector<T>& v, F fmt
 
 }  // namespace
 
+static Forest forest_from_document(const json::Value& doc);
+
 Forest parse_json_model(const char* text, size_t len) {
   json::Parser parser(text, len);
-  json::Value doc = parser.parse();
+  return forest_from_document(parser.parse());
+}
+
+// ---------------------------------------------------------------- UBJSON
+// Universal Binary JSON (draft 12) as xgboost >= 1.6 writes it for ".ubj": every scalar is
+// big-endian, object keys are length-prefixed without the 'S' marker, and the per-node arrays are
+// "optimized containers" ([$<type>#<count> followed by raw payloads).  The reader accepts the
+// whole standard, the writer emits what xgboost emits; both build on the JSON document model.
+
+namespace {
+
+struct UbjReader {
+  const uint8_t* p;
+  size_t len, off = 0;
+  [[noreturn]] void fail(const char* what) const { throw OhxError(std::string("UBJSON model: ") + what); }
+  uint8_t byte() {
+    if (off >= len) fail("truncated");
+    return p[off++];
+  }
+  uint8_t peek() const {
+    if (off >= len) throw OhxError("UBJSON model: truncated");
+    return p[off];
+  }
+  template <class T>
+  T be() {
+    if (off + sizeof(T) > len) fail("truncated");
+    uint8_t tmp[sizeof(T)];
+    for (size_t i = 0; i < sizeof(T); ++i) tmp[i] = p[off + sizeof(T) - 1 - i];
+    off += sizeof(T);
+    T v;
+    memcpy(&v, tmp, sizeof(T));
+    return v;
+  }
+  int64_t integer(uint8_t t) {
+    switch (t) {
+      case 'i': return be<int8_t>();
+      case 'U': return be<uint8_t>();
+      case 'I': return be<int16_t>();
+      case 'l': return be<int32_t>();
+      case 'L': return be<int64_t>();
+      default: fail("expected an integer type");
+    }
+  }
+  std::string text(uint8_t len_type) {
+    int64_t n = integer(len_type);
+    if (n < 0 || (uint64_t)n > len - off) fail("bad string length");
+    std::string s((const char*)p + off, (size_t)n);
+    off += (size_t)n;
+    return s;
+  }
+  json::Num number(uint8_t t) {
+    if (t == 'd') { float f = be<float>(); return {(double)f, f}; }
+    if (t == 'D') { double d = be<double>(); return {d, (float)d}; }
+    int64_t v = integer(t);
+    return {(double)v, (float)v};
+  }
+  static bool is_number(uint8_t t) { return strchr("iUIlLdD", (int)t) != nullptr && t != 0; }
+
+  json::Value value(uint8_t t) {
+    json::Value v;
+    if (t == 'Z') return v;
+    if (t == 'T' || t == 'F') { v.type = json::Value::Bool; v.b = (t == 'T'); return v; }
+    if (is_number(t)) { v.type = json::Value::Number; v.num = number(t); return v; }
+    if (t == 'C') { v.type = json::Value::String; v.str = std::string(1, (char)byte()); return v; }
+    if (t == 'S') { v.type = json::Value::String; v.str = text(byte()); return v; }
+    if (t == 'H') { v.type = json::Value::Number; std::string s = text(byte()); v.num = {strtod(s.c_str(), nullptr), strtof(s.c_str(), nullptr)}; return v; }
+    if (t == '[') {
+      uint8_t elem = 0;
+      int64_t count = -1;
+      if (peek() == '$') { ++off; elem = byte(); if (peek() != '#') fail("'$' without '#'"); }
+      if (peek() == '#') { ++off; count = integer(byte()); if (count < 0) fail("negative count"); }
+      if (elem != 0 && (is_number(elem) || elem == 'T' || elem == 'F')) {
+        v.type = json::Value::NumArray;
+        v.nums.reserve((size_t)count);
+        for (int64_t i = 0; i < count; ++i) {
+          if (elem == 'T') v.nums.push_back({1.0, 1.0f});
+          else if (elem == 'F') v.nums.push_back({0.0, 0.0f});
+          else v.nums.push_back(number(elem));
+        }
+        return v;
+      }
+      // general array; numeric-only ones are kept flat, like the JSON reader does
+      std::vector<json::Value> items;
+      bool numeric = true;
+      for (int64_t i = 0; count < 0 || i < count; ++i) {
+        uint8_t et = elem ? elem : byte();
+        if (count < 0 && et == ']') break;
+        if (et == 'N') { --i; continue; }
+        items.push_back(value(et));
+        numeric = numeric && (items.back().type == json::Value::Number || items.back().type == json::Value::Bool);
+      }
+      if (numeric) {
+        v.type = json::Value::NumArray;
+        for (auto& it : items) v.nums.push_back(it.type == json::Value::Bool ? json::Num{it.b ? 1.0 : 0.0, it.b ? 1.0f : 0.0f} : it.num);
+      } else {
+        v.type = json::Value::Array;
+        v.arr = std::move(items);
+      }
+      return v;
+    }
+    if (t == '{') {
+      v.type = json::Value::Object;
+      uint8_t elem = 0;
+      int64_t count = -1;
+      if (peek() == '$') { ++off; elem = byte(); if (peek() != '#') fail("'$' without '#'"); }
+      if (peek() == '#') { ++off; count = integer(byte()); if (count < 0) fail("negative count"); }
+      for (int64_t i = 0; count < 0 || i < count; ++i) {
+        uint8_t kt = byte();
+        if (count < 0 && kt == '}') break;
+        if (kt == 'N') { --i; continue; }
+        std::string key = text(kt);
+        uint8_t vt = elem ? elem : byte();
+        v.obj.emplace(std::move(key), value(vt));
+      }
+      return v;
+    }
+    fail("unknown type marker");
+  }
+};
+
+struct UbjWriter {
+  std::vector<uint8_t> out;
+  template <class T>
+  void be(T v) {
+    uint8_t tmp[sizeof(T)];
+    memcpy(tmp, &v, sizeof(T));
+    for (size_t i = 0; i < sizeof(T); ++i) out.push_back(tmp[sizeof(T) - 1 - i]);
+  }
+  void key(const std::string& k) { out.push_back('L'); be<int64_t>((int64_t)k.size()); out.insert(out.end(), k.begin(), k.end()); }
+  void str(const std::string& s) { out.push_back('S'); key(s); }
+  void kstr(const std::string& k, const std::string& v) { key(k); str(v); }
+  void integer(int64_t v) { out.push_back('L'); be<int64_t>(v); }
+  template <class T, class F>
+  void typed(const std::string& k, char marker, const std::vector<T>& v, F conv) {
+    key(k);
+    out.push_back('[');
+    out.push_back('$');
+    out.push_back((uint8_t)marker);
+    out.push_back('#');
+    out.push_back('L');
+    be<int64_t>((int64_t)v.size());
+    for (const T& x : v) conv(x);
+  }
+};
+
+}  // namespace
+
+Forest parse_ubjson_model(const uint8_t* p, size_t len) {
+  UbjReader r{p, len};
+  if (len == 0 || p[0] != '{') throw OhxError("UBJSON model: the document is not an object");
+  ++r.off;
+  return forest_from_document(r.value('{'));
+}
+
+std::vector<uint8_t> write_ubjson_model(const Forest& f) {
+  UbjWriter w;
+  auto f32 = [&](const std::string& k, const std::vector<float>& v) { w.typed(k, 'd', v, [&](float x) { w.be<float>(x); }); };
+  auto i32 = [&](const std::string& k, const std::vector<int32_t>& v) { w.typed(k, 'l', v, [&](int32_t x) { w.be<int32_t>(x); }); };
+  auto u8 = [&](const std::string& k, const std::vector<uint8_t>& v) { w.typed(k, 'U', v, [&](uint8_t x) { w.out.push_back(x); }); };
+  auto empty = [&](const std::string& k) { w.key(k); w.out.push_back('['); w.out.push_back(']'); };
+  auto fstr = [](float v) { char b[40]; snprintf(b, sizeof b, "%.9g", (double)v); return std::string(b); };
+  w.out.push_back('{');
+  w.key("learner"); w.out.push_back('{');
+  w.key("attributes"); w.out.push_back('{');
+  for (auto& kv : f.attributes) w.kstr(kv.first, kv.second);
+  w.out.push_back('}');
+  empty("feature_names");
+  empty("feature_types");
+  w.key("gradient_booster"); w.out.push_back('{');
+  w.key("model"); w.out.push_back('{');
+  w.key("gbtree_model_param"); w.out.push_back('{');
+  w.kstr("num_parallel_tree", "1");
+  w.kstr("num_trees", std::to_string(f.trees.size()));
+  w.kstr("size_leaf_vector", "0");
+  w.out.push_back('}');
+  i32("tree_info", f.tree_info);
+  w.key("trees"); w.out.push_back('[');
+  for (size_t ti = 0; ti < f.trees.size(); ++ti) {
+    const Tree& t = f.trees[ti];
+    w.out.push_back('{');
+    f32("base_weights", t.base_weight);
+    empty("categories"); empty("categories_nodes"); empty("categories_segments"); empty("categories_sizes");
+    u8("default_left", t.default_left);
+    w.key("id"); w.integer((int64_t)ti);
+    i32("left_children", t.left);
+    f32("loss_changes", t.loss_chg);
+    std::vector<int32_t> parents(t.size());
+    for (size_t i = 0; i < t.size(); ++i)
+      parents[i] = (i == 0 || t.parent[i] == -1) ? 2147483647 : (int32_t)((uint32_t)t.parent[i] & 0x7FFFFFFFu);
+    i32("parents", parents);
+    i32("right_children", t.right);
+    f32("split_conditions", t.value);
+    std::vector<int32_t> sidx(t.size());
+    for (size_t i = 0; i < t.size(); ++i) sidx[i] = (int32_t)t.feature[i];
+    i32("split_indices", sidx);
+    std::vector<uint8_t> stype(t.size(), 0);
+    u8("split_type", stype);
+    f32("sum_hessian", t.sum_hess);
+    w.key("tree_param"); w.out.push_back('{');
+    int32_t num_deleted = 0;
+    for (size_t i = 1; i < t.size(); ++i) num_deleted += t.deleted[i] ? 1 : 0;
+    w.kstr("num_deleted", std::to_string(num_deleted));
+    w.kstr("num_feature", std::to_string(t.num_feature ? t.num_feature : (int32_t)f.num_feature));
+    w.kstr("num_nodes", std::to_string(t.size()));
+    w.kstr("size_leaf_vector", "0");
+    w.out.push_back('}');
+    w.out.push_back('}');
+  }
+  w.out.push_back(']');
+  w.out.push_back('}');           // model
+  w.kstr("name", "gbtree");
+  w.out.push_back('}');           // gradient_booster
+  w.key("learner_model_param"); w.out.push_back('{');
+  w.kstr("base_score", fstr(f.base_score));
+  w.kstr("num_class", std::to_string(f.num_class));
+  w.kstr("num_feature", std::to_string(f.num_feature));
+  w.kstr("num_target", std::to_string(f.num_target));
+  w.out.push_back('}');
+  w.key("objective"); w.out.push_back('{');
+  w.kstr("name", f.objective);
+  w.key("reg_loss_param"); w.out.push_back('{'); w.kstr("scale_pos_weight", "1"); w.out.push_back('}');
+  w.out.push_back('}');
+  w.out.push_back('}');           // learner
+  w.key("version"); w.out.push_back('[');
+  w.integer(1); w.integer(6); w.integer(0);
+  w.out.push_back(']');
+  w.out.push_back('}');
+  return std::move(w.out);
+}
+
+static Forest forest_from_document(const json::Value& doc) {
   Forest f;
   if (const json::Value* ver = doc.find("version")) {
     if (ver->type == json::Value::NumArray && ver->nums.size() >= 2) {
@@ -527,7 +759,12 @@ static std::string file_extension(const std::string& path) {
 Forest load_model_buffer(const void* buf, size_t len) {
   if (buf == nullptr || len == 0) throw OhxError("empty model buffer");
   const uint8_t* p = (const uint8_t*)buf;
-  if (p[0] == '{') return parse_json_model((const char*)p, len);
+  if (p[0] == '{') {
+    // JSON text continues with white space, '"' or '}'; UBJSON with a length-type marker, '$' or '#'
+    const uint8_t c = len > 1 ? p[1] : (uint8_t)'}';
+    const bool ubj = c == 'L' || c == 'l' || c == 'I' || c == 'U' || c == 'i' || c == '$' || c == '#';
+    return ubj ? parse_ubjson_model(p, len) : parse_json_model((const char*)p, len);
+  }
   return parse_legacy_binary(p, len);
 }
 
@@ -536,7 +773,7 @@ Forest load_model_file(const std::string& path) {
   if (!in) throw OhxError("cannot open model file '" + path + "'");
   std::vector<char> data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
   std::string ext = file_extension(path);
-  if (ext == "ubj") throw OhxError("UBJSON model files are not supported; save the model as .json or legacy binary");
+  if (ext == "ubj") return parse_ubjson_model((const uint8_t*)data.data(), data.size());
   if (ext == "json") {
     if (data.size() < 2 || data[0] != '{') throw OhxError("'" + path + "' does not hold a JSON document");
     return parse_json_model(data.data(), data.size());
@@ -546,10 +783,12 @@ Forest load_model_file(const std::string& path) {
 
 void save_model_file(const Forest& f, const std::string& path) {
   std::string ext = file_extension(path);
-  if (ext == "ubj") throw OhxError("UBJSON model files are not supported; save the model as .json or legacy binary");
   std::ofstream out(path, std::ios::binary);
   if (!out) throw OhxError("cannot open '" + path + "' for writing");
-  if (ext == "json") {
+  if (ext == "ubj") {
+    std::vector<uint8_t> b = write_ubjson_model(f);
+    out.write((const char*)b.data(), (std::streamsize)b.size());
+  } else if (ext == "json") {
     std::string s = write_json_model(f);
     out.write(s.data(), (std::streamsize)s.size());
   } else {

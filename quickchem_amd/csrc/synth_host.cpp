@@ -235,8 +235,8 @@ int ohx_synth_model(uint32_t model_seed, int num_trees, int max_depth, int sampl
 
 void ohx_synth_free(uint8_t* buf) { free(buf); }
 
-// Convert a model file image between the two formats (host logic of
-// XGBoosterLoadModel/SaveModel without a booster): format as above.
+// Convert a model file image between the formats (host logic of XGBoosterLoadModel/SaveModel
+// without a booster): 0 = legacy binary, 1 = JSON, 2 = UBJSON.
 int ohx_model_convert(const uint8_t* in_buf, uint64_t in_len, int format, uint8_t** out_buf, uint64_t* out_len) {
   try {
     Forest f = load_model_buffer(in_buf, (size_t)in_len);
@@ -247,7 +247,7 @@ int ohx_model_convert(const uint8_t* in_buf, uint64_t in_len, int format, uint8_
       memcpy(*out_buf, s.data(), s.size());
       *out_len = s.size();
     } else {
-      std::vector<uint8_t> b = write_legacy_binary(f);
+      std::vector<uint8_t> b = format == 2 ? write_ubjson_model(f) : write_legacy_binary(f);
       *out_buf = (uint8_t*)malloc(b.size());
       memcpy(*out_buf, b.data(), b.size());
       *out_len = b.size();

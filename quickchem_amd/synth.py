@@ -125,11 +125,13 @@ def make_model(num_trees: int = 100, max_depth: int = 18, sample_log2: int = 20,
 
 
 def convert_model(image, fmt: str) -> np.ndarray:
-    """Legacy binary <-> JSON through the product's own reader and writer (host logic)."""
+    """Legacy binary / JSON / UBJSON ("binary", "json", "ubj") through the product's own readers and
+    writers (host logic)."""
     lib = _load()
     src = np.frombuffer(bytes(image), dtype=np.uint8) if not isinstance(image, np.ndarray) else image
     out, n = C.c_void_p(), C.c_uint64()
-    _check(lib.ohx_model_convert(src.ctypes.data, src.nbytes, 1 if fmt == "json" else 0, C.byref(out), C.byref(n)))
+    code = {"binary": 0, "json": 1, "ubj": 2}[fmt]
+    _check(lib.ohx_model_convert(src.ctypes.data, src.nbytes, code, C.byref(out), C.byref(n)))
     return _take(out, n.value)
 
 

@@ -131,3 +131,34 @@ def test_format_selection_falls_back_when_a_tree_is_too_big_for_super_nodes():
     assert big.num_nodes > 3 * 65536 and info["packed"] == 1, (big.num_nodes, info)
     small = synth.make_model(num_trees=2, max_depth=8, sample_log2=14, min_leaf=4, grid=synth.GRIDS["C12"])
     assert capi.Booster(model_buffer=small.image).info()["packed"] == 2
+
+
+def test_ubjson_round_trip_and_predictions(small_model, tmp_path):
+    """UBJSON (what xgboost >= 1.6 writes for ".ubj"): product writer -> product reader and the oracle's
+    own independent reader; same trees, same predictions, byte-identical legacy image after the trip."""
+    ubj = synth.convert_model(small_model.image, "ubj")
+    assert ubj[:2].tobytes() == b"{L" and len(ubj) < len(synth.convert_model(small_model.image, "json"))
+    assert np.array_equal(synth.convert_model(ubj, "binary"), small_model.image)
+    rows = synth.rows_cpu(synth.GRIDS["C12"], 0, 2048)
+    a = O.predict(O.load_model(small_model.image.tobytes()), rows, missing=synth.XX_MISS)
+    b = O.predict(O.load_model(ubj.tobytes()), rows, missing=synth.XX_MISS)
+    assert np.array_equal(helpers.bits(a), helpers.bits(b))
+    # through the ABI, by file extension
+    p_ubj, p_bin = tmp_path / "m.ubj", tmp_path / "m.bin"
+    bst = capi.Booster(model_buffer=small_model.image)
+    bst.save_model(str(p_ubj))
+    assert p_ubj.read_bytes() == ubj.tobytes()
+    capi.Booster(str(p_ubj)).save_model(str(p_bin))
+    assert p_bin.read_bytes() == small_model.image.tobytes()
+    # a hand-made document with standard small-int markers and unoptimised arrays is read too
+    doc = (b'{i\x07learner{i\x13learner_model_param{i\nbase_scoreSi\x045E-1i\x0bnum_featureSi\x011i\tnum_classSi\x010}'
+           b'i\tobjective{i\x04nameSi\x10reg:squarederror}'
+           b'i\x10gradient_booster{i\x04nameSi\x06gbtreei\x05model{i\x12gbtree_model_param{i\tnum_treesSi\x011}'
+           b'i\ttree_info[i\x00]i\x05trees[{i\ntree_param{i\tnum_nodesSi\x013i\x0bnum_featureSi\x011}'
+           b'i\rleft_children[i\x01i\xffi\xff]i\x0eright_children[i\x02i\xffi\xff]i\x07parents[l\x7f\xff\xff\xffi\x00i\x00]'
+           b'i\rsplit_indices[i\x00i\x00i\x00]i\x10split_conditions[d\x3f\x80\x00\x00d\xbf\x00\x00\x00d\x40\x00\x00\x00]'
+           b'i\x0cdefault_left[TFF]}]}}}}')
+    m = O.load_model(doc)
+    assert np.array_equal(O.predict(m, np.float32([[0.5], [1.0], [np.nan]])), np.float32([0.0, 2.5, 0.0]))
+    got = helpers.oracle_predict(synth.convert_model(doc, "binary"), np.float32([[0.5], [1.0], [np.nan]]), float("nan"))
+    assert np.array_equal(got, np.float32([0.0, 2.5, 0.0]))
