@@ -280,7 +280,9 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
         // faster than re-deriving the leaf every iteration, by 12-18 % on one device)
         leafv[c] = (!done[c] && ends) ? (leaf0 ? __uint_as_float(s[c].x) : thr1[c]) : leafv[c];
         done[c] = done[c] || ends;
-        cur[c] = done[c] ? cur[c] : idx;
+        // a finished lane parks on the tree's first super-node: lanes that agree on an address cost
+        // the L1 one tag look-up between them, a re-read of each lane's own node one per lane
+        cur[c] = done[c] ? base[c] : idx;
         more = more || !done[c];
       }
 #pragma unroll
