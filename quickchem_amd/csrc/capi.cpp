@@ -190,7 +190,10 @@ KernelKind pick_kernel(const BoosterObj& b) {
   if (k == "wide") return KernelKind::Wide;
   if (b.super_ok) {
     if (k == "super1") return KernelKind::Super1;
+    if (k == "super3") return KernelKind::Super3;
     if (k == "super4") return KernelKind::Super4;
+    if (k == "super5") return KernelKind::Super5;
+    if (k == "super6") return KernelKind::Super6;
     if (k == "super2" || k == "auto") return KernelKind::Super2;
   }
   if (!b.packed_ok) return KernelKind::Wide;
@@ -199,7 +202,7 @@ KernelKind pick_kernel(const BoosterObj& b) {
   return KernelKind::Packed2;
 }
 
-bool wants_super(const std::string& k) { return k == "auto" || k == "super1" || k == "super2" || k == "super4"; }
+bool wants_super(const std::string& k) { return k == "auto" || (k.size() == 6 && k.compare(0, 5, "super") == 0); }
 
 void invalidate_device_state(BoosterObj& b) {
   b.uploaded = false;
@@ -540,8 +543,8 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
   const std::string n(name), v(value);
   if (n == "ohx_kernel") {
     if (v != "auto" && v != "wide" && v != "packed1" && v != "packed2" && v != "packed4" && v != "super1" &&
-        v != "super2" && v != "super4")
-      throw OhxError("ohx_kernel must be one of auto, wide, packed1, packed2, packed4, super1, super2, super4");
+        v != "super2" && v != "super3" && v != "super4" && v != "super5" && v != "super6")
+      throw OhxError("ohx_kernel must be one of auto, wide, packed1, packed2, packed4, super1 .. super6");
     if (v != b->kernel_name) invalidate_device_state(*b);
     b->kernel_name = v;
   } else if (n == "ohx_top_levels") {
@@ -563,6 +566,29 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     int k = atoi(value);
     if (k < 0 || k > 1000000) throw OhxError("ohx_launches_per_residency must be >= 0");
     b->tune.launches_per_residency = k;
+  } else if (n == "ohx_grid") {
+    // "im,jm": the grid the rows of a DMatrix were gathered from (m = i + im*(j + jm*k)); "0,0" = unknown
+    int gi = -1, gj = -1;
+    if (sscanf(value, "%d,%d", &gi, &gj) != 2 || gi < 0 || gj < 0 || (gi == 0) != (gj == 0))
+      throw OhxError("ohx_grid must be \"im,jm\" (positive extents, or 0,0 for none)");
+    b->tune.grid_im = gi;
+    b->tune.grid_jm = gj;
+  } else if (n == "ohx_brick") {
+    // "bi,bj,bk": gridcells a wave takes along i, j, k (powers of two, product 64); "0,0,0" = 64 consecutive rows
+    int e[3] = {-1, -1, -1}, lg[3] = {0, 0, 0};
+    if (sscanf(value, "%d,%d,%d", &e[0], &e[1], &e[2]) != 3) throw OhxError("ohx_brick must be \"bi,bj,bk\"");
+    if (e[0] == 0 && e[1] == 0 && e[2] == 0) {
+      b->tune.brick_li = b->tune.brick_lj = b->tune.brick_lk = 0;
+    } else {
+      for (int q = 0; q < 3; ++q) {
+        if (e[q] < 1 || e[q] > 64 || (e[q] & (e[q] - 1))) throw OhxError("ohx_brick extents must be powers of two");
+        while ((1 << lg[q]) < e[q]) ++lg[q];
+      }
+      if (lg[0] + lg[1] + lg[2] != 6) throw OhxError("ohx_brick extents must multiply to 64");
+      b->tune.brick_li = lg[0];
+      b->tune.brick_lj = lg[1];
+      b->tune.brick_lk = lg[2];
+    }
   } else if (n == "ohx_lds_pad") {
     b->tune.lds_pad = atoi(value);
   } else if (n == "ohx_prefetch") {

@@ -163,14 +163,15 @@ bool emit_super(const Forest& f, SuperForest* out) {
   const SuperNode unused{0.0f, 0.0f, 0.0f, super_meta(kSuperLeaf, kSuperLeaf, kSuperLeaf, 0, 0, 0, 0)};
   struct Item {
     int32_t node;
-    uint32_t slot;  // relative to the tree base
+    uint32_t slot;   // relative to the tree base
+    uint32_t level;  // super-nodes above this one on its path
   };
   std::vector<Item> queue;
   for (const Tree& t : f.trees) {
     const uint32_t base = (uint32_t)out->nodes.size();
     SuperTreeHead head{base, 0u, 0.0f, 0u};
-    std::vector<SuperNode> sn(4, unused);  // group 0: the root (phase 0) and three unused slots
-    uint32_t next_group = 1;
+    std::vector<SuperNode> sn(8, unused);  // group 0: four fillers; group 1: where the walk starts
+    uint32_t next_group = 2;
     queue.clear();
     const bool root_is_leaf = t.left[0] == -1;
     const int phase = root_is_leaf ? 0 : choose_super_phase(t);
@@ -178,20 +179,19 @@ bool emit_super(const Forest& f, SuperForest* out) {
       // the root is evaluated from the head record; its children start the super-nodes
       head.root_meta = (t.feature[0] & 31u) | ((uint32_t)(t.default_left[0] ? 1u : 0u) << 5) | (1u << 8);
       head.root_thr = t.value[0];
-      const uint32_t grp = next_group++;
-      sn.resize((size_t)next_group * 4, unused);
-      queue.push_back({t.left[0], grp * 4 + 0});
-      queue.push_back({t.right[0], grp * 4 + 1});
+      queue.push_back({t.left[0], 4u, 0u});
+      queue.push_back({t.right[0], 5u, 0u});
     } else {
-      queue.push_back({0, 0u});
+      queue.push_back({0, 4u, 0u});
     }
-    out->heads.push_back(head);
     for (size_t qi = 0; qi < queue.size(); ++qi) {
       const Item it = queue[qi];
       const size_t n = (size_t)it.node;
       SuperNode s = unused;
       if (t.left[n] == -1) {
-        s.thr0 = t.value[n];
+        // a leaf on top: its value in all three slots, all three feature codes 31 (from `unused`),
+        // so that whichever child slot the walk looks at says "leaf" and holds the value
+        s.thr0 = s.thrL = s.thrR = t.value[n];
       } else {
         const size_t l = (size_t)t.left[n], r = (size_t)t.right[n];
         const bool l_int = t.left[l] != -1, r_int = t.left[r] != -1;
@@ -211,18 +211,20 @@ bool emit_super(const Forest& f, SuperForest* out) {
           meta |= grp << 18;
           sn.resize((size_t)next_group * 4, unused);
           if (l_int) {
-            queue.push_back({t.left[l], grp * 4 + 0});
-            queue.push_back({t.right[l], grp * 4 + 1});
+            queue.push_back({t.left[l], grp * 4 + 0, it.level + 1});
+            queue.push_back({t.right[l], grp * 4 + 1, it.level + 1});
           }
           if (r_int) {
-            queue.push_back({t.left[r], grp * 4 + 2});
-            queue.push_back({t.right[r], grp * 4 + 3});
+            queue.push_back({t.left[r], grp * 4 + 2, it.level + 1});
+            queue.push_back({t.right[r], grp * 4 + 3, it.level + 1});
           }
         }
         s.meta = meta;
       }
       sn[it.slot] = s;
+      if (it.level + 1 > head.steps) head.steps = it.level + 1;
     }
+    out->heads.push_back(head);
     out->nodes.insert(out->nodes.end(), sn.begin(), sn.end());
     if (out->nodes.size() >= 0xFFFFFFF0ull) throw OhxError("booster too large for the super-node format");
   }

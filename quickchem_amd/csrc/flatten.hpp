@@ -65,7 +65,8 @@ constexpr uint64_t kPackedMaxSlots = 1ull << 26;
 // texture addresser the same ~39 cycles whether a lane reads 4, 8 or 16 bytes
 // (tools/gather_microbench.hip), so fetching two levels at once halves the dominant cost.
 //   thr0 / thrL / thrR  split condition of the node / its left / its right child,
-//                       or the leaf value where that slot is a leaf
+//                       or the leaf value where that slot is a leaf; a super-node whose own
+//                       node is a leaf holds the value in all three (and three codes 31)
 //   meta  bits  0-4  feature of the left child  (31 = leaf)
 //               5,6,7 default_left of node / left child / right child
 //               8-12 feature of the node (31 = leaf); at bit 8 so that `meta & 0x1F00` IS the
@@ -92,7 +93,7 @@ struct SuperTreeHead {
   uint32_t base;        // index of the tree's first super-node (multiple of 4)
   uint32_t root_meta;   // bit 8: phase; bits 0-4: root feature; bit 5: root default_left
   float root_thr;
-  uint32_t pad;
+  uint32_t steps;       // super-nodes on the longest path: the walk's trip count (wave-uniform)
 };
 
 struct SuperForest {

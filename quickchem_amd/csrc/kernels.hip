@@ -52,6 +52,30 @@ __device__ __forceinline__ uint4 load_node16(__amdgpu_buffer_rsrc_t r, uint32_t 
 
 __device__ __forceinline__ bool is_inf(float v) { return __builtin_isinf(v); }
 
+// ------------------------------------------------------------------ lanes -> rows
+
+// Row of this lane in tile `tile_id` (TileShape, kernels.hpp).  Tiles are numbered brick-i
+// fastest, so the waves of a block and the blocks of a launch walk neighbouring bricks.
+__device__ __forceinline__ uint64_t tile_row(const TileShape& sh, uint64_t tile_id, int lane, uint64_t nrow,
+                                             bool* valid) {
+  if (sh.im == 0) {
+    const uint64_t row = tile_id * kWave + lane;
+    *valid = row < nrow;
+    return row;
+  }
+  uint32_t t = (uint32_t)tile_id;
+  const uint32_t bi = t % sh.nbi;
+  t /= sh.nbi;
+  const uint32_t bj = t % sh.nbj;
+  const uint32_t bk = t / sh.nbj;
+  const uint32_t l = (uint32_t)lane;
+  const uint32_t i = (bi << sh.li) + (l & ((1u << sh.li) - 1u));
+  const uint32_t j = (bj << sh.lj) + ((l >> sh.li) & ((1u << sh.lj) - 1u));
+  const uint32_t k = (bk << sh.lk) + (l >> (sh.li + sh.lj));
+  *valid = i < sh.im && j < sh.jm && k < sh.nk;
+  return (uint64_t)i + (uint64_t)sh.im * ((uint64_t)j + (uint64_t)sh.jm * (uint64_t)k);
+}
+
 // ------------------------------------------------------------------ tile fill
 
 // Row-major rows -> LDS tile[f * 64 + lane].  `missing` values become NaN so the
@@ -209,11 +233,54 @@ __device__ __forceinline__ float walk_wide_tile(const uint4* __restrict__ nodes,
 // load: the wait would land there), keeps every gather a single global_load_dwordx4 and leaves
 // the other chains' gathers in flight behind a counted vmcnt.
 
+// One step (two tree levels) of all chains.  There is no "finished" state: a lane that has taken its
+// leaf simply walks on, and emit_super guarantees that it lands on filler super-nodes (all codes 31,
+// all values +0.0, group 0 = four fillers) from then on, so OR-ing "the child's value if its code
+// is 31" into the lane's leaf bits adds the real leaf exactly once and zero bits afterwards.  The
+// fillers of one tree share a cache line or two, so lanes that are done cost the L1 next to nothing.
+// LAST: the tree's final step - nothing is fetched after it, only the leaf is taken.
+template <int CHAINS, bool HAS_MISSING, bool LAST>
+__device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[CHAINS], uint32_t (&leafb)[CHAINS],
+                                           const char* __restrict__ tile_b) {
+  float x0[CHAINS], x1[CHAINS];
+  uint32_t thr1[CHAINS], f1[CHAINS];
+  bool l0[CHAINS];
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) {
+    asm volatile("" : "+v"(s[c]));   // one 128-bit tuple: see "pin_super" above
+    // meta & 0x1F00 is the byte offset of the node's feature row; a leaf (feature 31) reads a
+    // row that belongs to nobody (past the allocation an LDS read returns zero) and the
+    // value is not used
+    x0[c] = *reinterpret_cast<const float*>(tile_b + (s[c].w & 0x1F00u));
+  }
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) {
+    const uint32_t w = s[c].w;
+    bool l = x0[c] < __uint_as_float(s[c].x);
+    if (HAS_MISSING) l = l || ((x0[c] != x0[c]) && ((w >> 5) & 1u));
+    l0[c] = l;
+    thr1[c] = l ? s[c].y : s[c].z;
+    f1[c] = (w >> (l ? 0u : 13u)) & 31u;
+    if (!LAST) x1[c] = *reinterpret_cast<const float*>(tile_b + (f1[c] << 8));
+  }
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) {
+    const uint32_t w = s[c].w;
+    leafb[c] |= (f1[c] == 31u) ? thr1[c] : 0u;
+    if (!LAST) {
+      bool l1 = x1[c] < __uint_as_float(thr1[c]);
+      if (HAS_MISSING) l1 = l1 || ((x1[c] != x1[c]) && ((w >> (l0[c] ? 6u : 7u)) & 1u));
+      rel[c] = ((w >> 18) << 2) + (l0[c] ? 0u : 2u) + (l1 ? 0u : 1u);
+    }
+  }
+}
+
 template <int CHAINS, bool HAS_MISSING>
 __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const SuperTreeHead* __restrict__ heads,
                                             uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile) {
   if (t0 >= t1) return acc;
   const u32x4* __restrict__ nodes_v = reinterpret_cast<const u32x4*>(nodes);
+  const char* tile_b = reinterpret_cast<const char*>(tile);
   // tree heads are wave-uniform (scalar loads); the next group's are fetched a whole walk ahead
   SuperTreeHead hn[CHAINS];
 #pragma unroll
@@ -227,78 +294,46 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
       hn[c] = heads[tn < t1 ? tn : t1 - 1];               // clamp: a duplicate walk is discarded below
     }
     u32x4 s[CHAINS];
-    uint32_t base[CHAINS], cur[CHAINS];
-    float leafv[CHAINS], xr[CHAINS];
-    bool done[CHAINS];
+    // a lane's place in its tree: super-node index relative to the tree's first; the tree's own
+    // address is wave-uniform, so a gather is base (SGPR pair) + 32-bit byte offset
+    const char* tb[CHAINS];
+    uint32_t rel[CHAINS], leafb[CHAINS];
+    float xr[CHAINS];
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) xr[c] = tile[(h[c].root_meta & 31u) * kWave];
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) {
       bool l = xr[c] < h[c].root_thr;
       if (HAS_MISSING) l = l || ((xr[c] != xr[c]) && (h[c].root_meta & 32u));
-      base[c] = h[c].base;
-      cur[c] = (h[c].root_meta & 0x100u) ? h[c].base + 4u + (l ? 0u : 1u) : h[c].base;
-      leafv[c] = 0.0f;
-      done[c] = false;
+      tb[c] = reinterpret_cast<const char*>(nodes_v + h[c].base);
+      // group 1 holds the root's super-node (phase 0) or those of its two children (phase 1)
+      rel[c] = 4u + (((h[c].root_meta & 0x100u) && !l) ? 1u : 0u);
+      leafb[c] = 0u;
     }
+    // The trip count is the tree's (a scalar from its head), not a vote of the lanes: no branch
+    // waits for the chains' compares, and the last step fetches nothing.
+    uint32_t nsteps = h[0].steps;
 #pragma unroll
-    for (int c = 0; c < CHAINS; ++c) s[c] = nodes_v[cur[c]];
-    const char* tile_b = reinterpret_cast<const char*>(tile);
-    bool more;
-    do {
-      float x0[CHAINS], x1[CHAINS], thr1[CHAINS];
-      bool l0[CHAINS];
-      uint32_t f1[CHAINS];
+    for (int c = 1; c < CHAINS; ++c) nsteps = h[c].steps > nsteps ? h[c].steps : nsteps;
 #pragma unroll
-      for (int c = 0; c < CHAINS; ++c) {
-        asm volatile("" : "+v"(s[c]));   // one 128-bit tuple: see "pin_super" above
-        // meta & 0x1F00 is the byte offset of the node's feature row; a leaf (feature 31) reads a
-        // row that belongs to nobody (past the allocation an LDS read returns zero) and the
-        // value is not used
-        x0[c] = *reinterpret_cast<const float*>(tile_b + (s[c].w & 0x1F00u));
-      }
+    for (int c = 0; c < CHAINS; ++c) s[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)(rel[c] << 4));
+    for (uint32_t step = 1; step < nsteps; ++step) {
+      super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
 #pragma unroll
-      for (int c = 0; c < CHAINS; ++c) {
-        const uint32_t w = s[c].w;
-        bool l = x0[c] < __uint_as_float(s[c].x);
-        if (HAS_MISSING) l = l || ((x0[c] != x0[c]) && ((w >> 5) & 1u));
-        l0[c] = l;
-        thr1[c] = __uint_as_float(l ? s[c].y : s[c].z);
-        f1[c] = (w >> (l ? 0u : 13u)) & 31u;
-        x1[c] = *reinterpret_cast<const float*>(tile_b + (f1[c] << 8));
-      }
-      more = false;
-#pragma unroll
-      for (int c = 0; c < CHAINS; ++c) {
-        const uint32_t w = s[c].w;
-        bool l1 = x1[c] < thr1[c];
-        if (HAS_MISSING) l1 = l1 || ((x1[c] != x1[c]) && ((w >> (l0[c] ? 6u : 7u)) & 1u));
-        const uint32_t idx = base[c] + ((w >> 18) << 2) + (l0[c] ? 0u : 2u) + (l1 ? 0u : 1u);
-        const bool leaf0 = (w & 0x1F00u) == 0x1F00u;
-        const bool ends = leaf0 || f1[c] == 31u;
-        // a finished chain keeps its leaf and keeps re-reading where it stopped (measured
-        // faster than re-deriving the leaf every iteration, by 12-18 % on one device)
-        leafv[c] = (!done[c] && ends) ? (leaf0 ? __uint_as_float(s[c].x) : thr1[c]) : leafv[c];
-        done[c] = done[c] || ends;
-        // a finished lane parks on the tree's first super-node: lanes that agree on an address cost
-        // the L1 one tag look-up between them, a re-read of each lane's own node one per lane
-        cur[c] = done[c] ? base[c] : idx;
-        more = more || !done[c];
-      }
-#pragma unroll
-      for (int c = 0; c < CHAINS; ++c) s[c] = nodes_v[cur[c]];
-    } while (__any(more));
+      for (int c = 0; c < CHAINS; ++c) s[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)(rel[c] << 4));
+    }
+    super_step<CHAINS, HAS_MISSING, true>(s, rel, leafb, tile_b);
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c)
-      if (t + c < t1) acc += leafv[c];
+      if (t + c < t1) acc += __uint_as_float(leafb[c]);
   }
   return acc;
 }
 
 // FMT: 0 = wide 16-byte nodes, 1 = packed 8-byte nodes, 2 = 16-byte super-nodes
 template <int FMT, int CHAINS>
-__device__ __forceinline__ float walk_tile(const DeviceForest& fr, uint32_t t0, uint32_t t1, const float* tile,
-                                           bool wave_has_missing) {
+__device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads, uint32_t t0,
+                                           uint32_t t1, const float* tile, bool wave_has_missing) {
   float acc = fr.base_score;
   if constexpr (FMT == 1) {
     const __amdgpu_buffer_rsrc_t nodes = make_rsrc(fr.packed, fr.packed_bytes);
@@ -307,8 +342,8 @@ __device__ __forceinline__ float walk_tile(const DeviceForest& fr, uint32_t t0, 
   } else if constexpr (FMT == 2) {
     // plain 128-bit global loads: measured 8 % faster than buffer loads on the divergent deep levels
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.super);
-return wave_has_missing ? walk_super<CHAINS, true>(nodes, fr.super_heads, t0, t1, acc, tile)
-                            : walk_super<CHAINS, false>(nodes, fr.super_heads, t0, t1, acc, tile);
+    return wave_has_missing ? walk_super<CHAINS, true>(nodes, heads, t0, t1, acc, tile)
+                            : walk_super<CHAINS, false>(nodes, heads, t0, t1, acc, tile);
   } else {
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
     return wave_has_missing ? walk_wide_tile<true>(nodes, fr.roots, t0, t1, acc, tile)
@@ -321,7 +356,11 @@ return wave_has_missing ? walk_super<CHAINS, true>(nodes, fr.super_heads, t0, t1
 // AoS rows in, margins out.  PREFETCH27: 27-column rows, next tile's rows prefetched into
 // registers during the walk (used when a launch gives every wave more than one tile).
 template <int FMT, int CHAINS, bool PREFETCH27>
-__global__ __launch_bounds__(kBlock) void predict_rows_tile_kernel(DeviceForest fr, PredictArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS > 5 ? 4 : 5))) void predict_rows_tile_kernel(
+    DeviceForest fr, PredictArgs a, const SuperTreeHead* __restrict__ heads, float* __restrict__ out) {
+  // `heads` (= fr.super_heads) and `out` (= a.out) are kernel arguments of their own so that they carry
+  // noalias: with the margins' stores provably elsewhere, the wave-uniform head records stay scalar
+  // loads (as members of the by-value structs they turn into one more vector load per walk)
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -337,35 +376,37 @@ __global__ __launch_bounds__(kBlock) void predict_rows_tile_kernel(DeviceForest 
   if constexpr (PREFETCH27) {
     uint64_t tile_id = a.tile_begin + wave_id;
     Row27 regs;
+    bool valid = false;
+    uint64_t row = 0;
     if (tile_id < a.tile_end) {
-      const uint64_t row = tile_id * kWave + lane;
-      load_row27(regs, a.rows, row < a.nrow ? row : a.nrow - 1);
+      row = tile_row(a.shape, tile_id, lane, a.nrow, &valid);
+      load_row27(regs, a.rows, valid ? row : 0);
     }
     while (tile_id < a.tile_end) {
-      const uint64_t row = tile_id * kWave + lane;
-      const bool valid = row < a.nrow;
       const bool lane_nan = store_row27(tile, regs, valid, a.missing, missing_is_nan, a.flags);
       const uint64_t next = tile_id + nwaves;
+      const uint64_t this_row = row;
+      const bool this_valid = valid;
       if (next < a.tile_end) {
-        const uint64_t nrow = next * kWave + lane;
-        load_row27(regs, a.rows, nrow < a.nrow ? nrow : a.nrow - 1);   // in flight during the walk
+        row = tile_row(a.shape, next, lane, a.nrow, &valid);
+        load_row27(regs, a.rows, valid ? row : 0);   // in flight during the walk
       }
       const bool wave_nan = __any(lane_nan);
-      const float acc = walk_tile<FMT, CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
-      if (valid) __builtin_nontemporal_store(acc, a.out + row);
+      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan);
+      if (this_valid) __builtin_nontemporal_store(acc, out + this_row);
       tile_id = next;
     }
     return;
   }
   for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
-    const uint64_t row = tile_id * kWave + lane;
-    const bool valid = row < a.nrow;
+    bool valid;
+    const uint64_t row = tile_row(a.shape, tile_id, lane, a.nrow, &valid);
     const bool lane_nan = fill_tile_rows(tile, a.rows, row, valid, a.ncol, fr.num_feature, a.missing,
                                          missing_is_nan, a.flags);
     const bool wave_nan = __any(lane_nan);
     // the tile is private to this wave: its own LDS writes are ordered before its reads
-    const float acc = walk_tile<FMT, CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
-    if (valid) __builtin_nontemporal_store(acc, a.out + row);
+    const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan);
+    if (valid) __builtin_nontemporal_store(acc, out + row);
   }
 }
 
@@ -408,7 +449,9 @@ __global__ __launch_bounds__(kBlock) void predict_rows_direct_kernel(DeviceFores
 // applies PL/100 (OH_GridCompMod.F90:314), walks, writes 10**pred * OHscale
 // (OH_GridCompMod.F90:369,1569) into OH_ML(i,j,k1..k2).
 template <int FMT, int CHAINS>
-__global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr, FieldsArgs a) {
+__global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr, FieldsArgs a, const SuperTreeHead* __restrict__ heads,
+                                                                float* __restrict__ out,
+                                                                float* __restrict__ margin_out) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -422,8 +465,8 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
   const float qnan = __builtin_nanf("");
   for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
-    const uint64_t m = tile_id * kWave + lane;
-    const bool valid = m < nrow;
+    bool valid;
+    const uint64_t m = tile_row(a.shape, tile_id, lane, nrow, &valid);
     const uint64_t col = valid ? m % plane : 0;
     bool lane_nan = false, any_inf = false;
     for (uint32_t f = 0; f < fr.num_feature; ++f) {
@@ -441,14 +484,14 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
     }
     if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
     const bool wave_nan = __any(lane_nan);
-    const float acc = walk_tile<FMT, CHAINS>(fr, a.tree_begin, a.tree_end, tile, wave_nan);
+    const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan);
     if (valid) {
-      if (a.margin_out) a.margin_out[m] = acc;
+      if (margin_out) margin_out[m] = acc;
       float oh = acc;
       // 10.0**x rounded once from double: agrees with a correctly rounded powf
       if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);
       oh = oh * a.scale;
-      a.out[slab_out + m] = oh;
+      out[slab_out + m] = oh;
     }
   }
 }
@@ -625,11 +668,10 @@ size_t tile_lds_bytes(uint32_t num_feature) {
 }
 
 template <class K>
-int tile_grid(K kernel, size_t lds_bytes, uint64_t nrow, int num_cus) {
+int tile_grid(K kernel, size_t lds_bytes, uint64_t ntiles, int num_cus) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes) != hipSuccess || per_cu < 1)
     per_cu = 1;
-  const uint64_t ntiles = (nrow + kWave - 1) / kWave;
   uint64_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
   const uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
   if (blocks > cap) blocks = cap;
@@ -652,13 +694,20 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
   lds += (size_t)tune.lds_pad;
   hipError_t e = ensure_lds(kernel, lds);
   if (e != hipSuccess) return e;
-  const int grid = tile_grid(kernel, lds, a.nrow, num_cus);
-  const uint64_t ntiles = (a.nrow + kWave - 1) / kWave;
+  // bricks when the caller named the grid and the rows are whole levels of it
+  const uint64_t plane = (uint64_t)(tune.grid_im > 0 ? tune.grid_im : 0) * (uint64_t)(tune.grid_jm > 0 ? tune.grid_jm : 0);
+  if (plane > 0 && tune.brick_li + tune.brick_lj + tune.brick_lk == 6 && a.nrow % plane == 0 &&
+      a.nrow / plane < (1u << 20))
+    a.shape.set_grid((uint32_t)tune.grid_im, (uint32_t)tune.grid_jm, (uint32_t)(a.nrow / plane), (uint32_t)tune.brick_li,
+                     (uint32_t)tune.brick_lj, (uint32_t)tune.brick_lk);
+  if (a.shape.ntiles(a.nrow) >= 0xFFFFFFFFull) a.shape = TileShape();   // tile_row numbers bricks in 32 bits
+  const uint64_t ntiles = a.shape.ntiles(a.nrow);
+  const int grid = tile_grid(kernel, lds, ntiles, num_cus);
   a.xcd_remap = tune.xcd_remap;
   if (tune.launches_per_residency <= 0) {
     a.tile_begin = 0;
     a.tile_end = ntiles;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, fr, a, fr.super_heads, a.out);
     return hipGetLastError();
   }
   const uint64_t per_launch = (uint64_t)grid * kWavesPerBlock * (uint64_t)tune.launches_per_residency;
@@ -667,7 +716,7 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
     a.tile_end = t0 + per_launch < ntiles ? t0 + per_launch : ntiles;
     const uint64_t blocks = (a.tile_end - a.tile_begin + kWavesPerBlock - 1) / kWavesPerBlock;
     hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < (uint64_t)grid ? blocks : (uint64_t)grid)), dim3(kBlock), lds,
-                       stream, fr, a);
+                       stream, fr, a, fr.super_heads, a.out);
   }
   return hipGetLastError();
 }
@@ -683,7 +732,10 @@ const char* kernel_kind_name(KernelKind k) {
     case KernelKind::Packed4: return "packed4";
     case KernelKind::Super1: return "super1";
     case KernelKind::Super2: return "super2";
+    case KernelKind::Super3: return "super3";
     case KernelKind::Super4: return "super4";
+    case KernelKind::Super5: return "super5";
+    case KernelKind::Super6: return "super6";
   }
   return "?";
 }
@@ -693,7 +745,8 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
   if (a.nrow == 0) return hipSuccess;
   const size_t lds = tile_lds_bytes(fr.num_feature);
   const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && a.ncol <= fr.num_feature;
-  const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super4;
+  const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
+                        kind == KernelKind::Super4 || kind == KernelKind::Super5 || kind == KernelKind::Super6;
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
   if (a.pred_leaf || kind == KernelKind::Wide || !tile_ok || (!is_super && fr.packed == nullptr)) {
     if (fr.wide == nullptr) return hipErrorInvalidValue;
@@ -712,7 +765,10 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
     case KernelKind::Packed2: OHX_ROWS(1, 2);
     case KernelKind::Packed4: OHX_ROWS(1, 4);
     case KernelKind::Super1: OHX_ROWS(2, 1);
+    case KernelKind::Super3: OHX_ROWS(2, 3);
     case KernelKind::Super4: OHX_ROWS(2, 4);
+    case KernelKind::Super5: OHX_ROWS(2, 5);
+    case KernelKind::Super6: OHX_ROWS(2, 6);
     default: OHX_ROWS(2, 2);
   }
 #undef OHX_ROWS
@@ -725,8 +781,12 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
                                hipStream_t stream, const LaunchTuning& tune) {
   hipError_t e = ensure_lds(kernel, lds);
   if (e != hipSuccess) return e;
-  const int grid = tile_grid(kernel, lds, nrow, num_cus);
-  const uint64_t ntiles = (nrow + kWave - 1) / kWave;
+  if (tune.brick_li + tune.brick_lj + tune.brick_lk == 6)
+    a.shape.set_grid((uint32_t)a.im, (uint32_t)a.jm, (uint32_t)(a.k2 - a.k1 + 1), (uint32_t)tune.brick_li,
+                     (uint32_t)tune.brick_lj, (uint32_t)tune.brick_lk);
+  if (a.shape.ntiles(nrow) >= 0xFFFFFFFFull) a.shape = TileShape();
+  const uint64_t ntiles = a.shape.ntiles(nrow);
+  const int grid = tile_grid(kernel, lds, ntiles, num_cus);
   const uint64_t per_launch = tune.launches_per_residency <= 0
                                   ? ntiles
                                   : (uint64_t)grid * kWavesPerBlock * (uint64_t)tune.launches_per_residency;
@@ -735,7 +795,7 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
     a.tile_end = t0 + per_launch < ntiles ? t0 + per_launch : ntiles;
     const uint64_t blocks = (a.tile_end - a.tile_begin + kWavesPerBlock - 1) / kWavesPerBlock;
     hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < (uint64_t)grid ? blocks : (uint64_t)grid)), dim3(kBlock), lds,
-                       stream, fr, a);
+                       stream, fr, a, fr.super_heads, a.out, a.margin_out);
   }
   return hipGetLastError();
 }
@@ -746,7 +806,8 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   const uint64_t nrow = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)(a.k2 - a.k1 + 1);
   const size_t lds = tile_lds_bytes(fr.num_feature);
   if (fr.num_feature < 1 || lds > 160 * 1024) return hipErrorInvalidValue;
-  const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super4;
+  const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
+                        kind == KernelKind::Super4 || kind == KernelKind::Super5 || kind == KernelKind::Super6;
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
   const bool use_wide = kind == KernelKind::Wide || (!is_super && fr.packed == nullptr);
   if (use_wide && fr.wide == nullptr) return hipErrorInvalidValue;
@@ -758,7 +819,10 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
     case KernelKind::Packed2: OHX_LAUNCH_FIELDS(1, 2);
     case KernelKind::Packed4: OHX_LAUNCH_FIELDS(1, 4);
     case KernelKind::Super1: OHX_LAUNCH_FIELDS(2, 1);
+    case KernelKind::Super3: OHX_LAUNCH_FIELDS(2, 3);
     case KernelKind::Super4: OHX_LAUNCH_FIELDS(2, 4);
+    case KernelKind::Super5: OHX_LAUNCH_FIELDS(2, 5);
+    case KernelKind::Super6: OHX_LAUNCH_FIELDS(2, 6);
     default: OHX_LAUNCH_FIELDS(2, 2);
   }
 #undef OHX_LAUNCH_FIELDS

@@ -29,6 +29,25 @@ struct DeviceForest {
   uint32_t super_bytes = 0;
 };
 
+// Which 64 rows a wave takes.  Without a grid (im == 0) tile t is rows 64t .. 64t+63.  With the
+// grid the rows were gathered from (m = i + im*(j + jm*k), OH_GridCompMod.F90:309-345) a tile is a
+// brick of 2^li x 2^lj x 2^lk neighbouring gridcells: neighbours in all three directions have
+// similar features, so the lanes of a wave share more tree nodes (fewer L1 tag look-ups per
+// gather) than 64 cells of one latitude line do.  Bricks overhang the grid where
+// an extent is not a multiple of the brick's; those lanes idle.
+struct TileShape {
+  uint32_t im = 0, jm = 0, nk = 0;
+  uint32_t li = 2, lj = 2, lk = 2;      // li + lj + lk == 6
+  uint32_t nbi = 0, nbj = 0, nbk = 0;   // bricks along i, j, k
+  uint64_t ntiles(uint64_t nrow) const { return im ? (uint64_t)nbi * nbj * nbk : (nrow + 63) / 64; }
+  void set_grid(uint32_t im_, uint32_t jm_, uint32_t nk_, uint32_t li_, uint32_t lj_, uint32_t lk_) {
+    im = im_; jm = jm_; nk = nk_; li = li_; lj = lj_; lk = lk_;
+    nbi = (im + (1u << li) - 1) >> li;
+    nbj = (jm + (1u << lj) - 1) >> lj;
+    nbk = (nk + (1u << lk) - 1) >> lk;
+  }
+};
+
 struct PredictArgs {
   const float* rows = nullptr;  // [nrow][ncol] row-major (the reference's xx_carr(27,N))
   uint64_t nrow = 0;
@@ -41,6 +60,7 @@ struct PredictArgs {
   uint64_t tile_begin = 0;      // first 64-row tile of this launch (tile kernels)
   uint64_t tile_end = 0;        // one past the last tile of this launch
   int xcd_remap = 1;            // give each XCD a contiguous range of tiles
+  TileShape shape;              // lanes -> rows
 };
 
 struct LaunchTuning {
@@ -51,6 +71,10 @@ struct LaunchTuning {
   int xcd_remap = 1;
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
+  // rows API: the grid the rows were gathered from (XGBoosterSetParam "ohx_grid" = "im,jm"); used
+  // when the row count is a whole number of (im x jm) levels.  0 = unknown, tiles are 64 rows.
+  int grid_im = 0, grid_jm = 0;
+  int brick_li = 2, brick_lj = 2, brick_lk = 2;   // log2 extents of a wave's brick; all 0 = no bricks
 };
 
 // 27 SoA fields of the MAPL state (OH_GridCompMod.F90:313-339), device pointers.
@@ -70,6 +94,7 @@ struct FieldsArgs {
   float* margin_out = nullptr; // optional [N] raw margins in slab row order
   uint32_t* flags = nullptr;
   uint64_t tile_begin = 0, tile_end = 0;   // 64-row tiles of this launch
+  TileShape shape;             // lanes -> gridcells of the slab
 };
 
 // OH Run1's feature engineering and post-processing (include/ohxgb.h part 3), device pointers.
@@ -102,7 +127,7 @@ hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_
 hipError_t launch_k_slab(const SlabArgs& a, hipStream_t stream);
 hipError_t launch_post_process(const PostArgs& a, hipStream_t stream);
 
-enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super4 };
+enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super3, Super4, Super5, Super6 };
 
 const char* kernel_kind_name(KernelKind k);
 
