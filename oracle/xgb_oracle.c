@@ -456,6 +456,15 @@ ORACLE_EXPORT int XGBoosterSetParam(void* h, const char* name, const char* value
   return 0;
 }
 
+/* The product's layout hint (include/ohxgb.h); predictions do not depend on it, so the oracle
+ * only checks the arguments. */
+ORACLE_EXPORT int OHXDMatrixSetGrid(void* dmat, int im, int jm, uint64_t row0) {
+  (void)row0;
+  if (dmat == NULL) return fail("OHXDMatrixSetGrid: NULL handle");
+  if (im < 0 || jm < 0 || (im == 0) != (jm == 0)) return fail("OHXDMatrixSetGrid: bad extents");
+  return 0;
+}
+
 /*
  * CPU restatement of the product's fused entry point (include/ohxgb.h
  * OHXBoosterPredictFields), so the Fortran mock driver links against the oracle

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "XGBGetLastError", "XGDMatrixCreateFromMat", "XGDMatrixFree", "XGDMatrixNumRow", "XGDMatrixNumCol",
     "XGDMatrixSaveBinary", "XGDMatrixCreateFromFile", "XGBoosterCreate", "XGBoosterFree", "XGBoosterLoadModel",
     "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
-    "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXBoosterPredictDevice", "OHXBoosterCheck",
+    "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device",
     "OHXBoosterGetInfo", "OHXSynthRowsDevice",
     "OHXSynthFieldDevice", "OHXInjectMissingDevice",
@@ -94,6 +94,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.XGBoosterSetParam.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.OHXDeviceCount.argtypes = [C.POINTER(i32)]
     lib.OHXDMatrixCreateFromDevice.argtypes = [vp, u64, u64, f32, C.POINTER(vp)]
+    lib.OHXDMatrixSetGrid.argtypes = [vp, i32, i32, u64]
     lib.OHXBoosterPredictDevice.argtypes = [vp, vp, i32, C.c_uint, vp, vp]
     lib.OHXBoosterCheck.argtypes = [vp, vp]
     lib.OHXBoosterPredictFields.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), i32, i32, i32, i32, i32, i32, i32,
@@ -147,6 +148,11 @@ class DMatrix:
         out = C.c_uint64()
         check(self.lib, self.lib.XGDMatrixNumCol(self.handle, C.byref(out)))
         return out.value
+
+    def set_grid(self, im: int, jm: int, row0: int = 0) -> "DMatrix":
+        """OHXDMatrixSetGrid: the rows are rows row0.. of the (im, jm, *) gather (speed only)."""
+        check(self.lib, self.lib.OHXDMatrixSetGrid(self.handle, im, jm, row0))
+        return self
 
     def save_binary(self, fname: str) -> None:
         check(self.lib, self.lib.XGDMatrixSaveBinary(self.handle, fname.encode(), 1))

@@ -135,6 +135,9 @@ struct DMatrixObj {
   const float* d_data = nullptr;  // device
   DevBuf<float> owned;            // set when the matrix owns its storage
   int device = -1;
+  // OHXDMatrixSetGrid: the rows are grid rows grid_row0 .. of an (im,jm,*) grid; 0 = not said
+  int grid_im = 0, grid_jm = 0;
+  uint64_t grid_row0 = 0;
 };
 
 struct BoosterObj {
@@ -329,7 +332,11 @@ void launch_predict_checked(BoosterObj& b, const DMatrixObj& d, int option_mask,
   a.out = d_out;
   a.pred_leaf = pred_leaf;
   a.flags = b.d_flags.p;
-  HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, b.tune));
+  LaunchTuning tune = b.tune;
+  tune.grid_im = d.grid_im;
+  tune.grid_jm = d.grid_jm;
+  tune.grid_row0 = d.grid_row0;
+  HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, tune));
 }
 
 }  // namespace
@@ -388,6 +395,16 @@ int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong nc
   d->d_data = d_data;
   d->device = dev.ordinal;
   *out = d.release();
+  API_END();
+}
+
+int OHXDMatrixSetGrid(DMatrixHandle handle, int im, int jm, bst_ulong row0) {
+  API_BEGIN();
+  DMatrixObj* d = as_dmat(handle);
+  if (im < 0 || jm < 0 || (im == 0) != (jm == 0)) throw OhxError("OHXDMatrixSetGrid: im and jm must both be positive (or both 0)");
+  d->grid_im = im;
+  d->grid_jm = jm;
+  d->grid_row0 = im ? row0 : 0;
   API_END();
 }
 
@@ -566,18 +583,15 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     int k = atoi(value);
     if (k < 0 || k > 1000000) throw OhxError("ohx_launches_per_residency must be >= 0");
     b->tune.launches_per_residency = k;
-  } else if (n == "ohx_grid") {
-    // "im,jm": the grid the rows of a DMatrix were gathered from (m = i + im*(j + jm*k)); "0,0" = unknown
-    int gi = -1, gj = -1;
-    if (sscanf(value, "%d,%d", &gi, &gj) != 2 || gi < 0 || gj < 0 || (gi == 0) != (gj == 0))
-      throw OhxError("ohx_grid must be \"im,jm\" (positive extents, or 0,0 for none)");
-    b->tune.grid_im = gi;
-    b->tune.grid_jm = gj;
   } else if (n == "ohx_brick") {
-    // "bi,bj,bk": gridcells a wave takes along i, j, k (powers of two, product 64); "0,0,0" = 64 consecutive rows
+    // "bi,bj,bk": gridcells a wave takes along i, j, k (powers of two, product 64); "auto" = chosen per
+    // call for the fewest idle lanes; "0,0,0" = 64 consecutive rows
     int e[3] = {-1, -1, -1}, lg[3] = {0, 0, 0};
-    if (sscanf(value, "%d,%d,%d", &e[0], &e[1], &e[2]) != 3) throw OhxError("ohx_brick must be \"bi,bj,bk\"");
-    if (e[0] == 0 && e[1] == 0 && e[2] == 0) {
+    if (v == "auto") {
+      b->tune.brick_li = b->tune.brick_lj = b->tune.brick_lk = -1;
+    } else if (sscanf(value, "%d,%d,%d", &e[0], &e[1], &e[2]) != 3) {
+      throw OhxError("ohx_brick must be \"bi,bj,bk\" or \"auto\"");
+    } else if (e[0] == 0 && e[1] == 0 && e[2] == 0) {
       b->tune.brick_li = b->tune.brick_lj = b->tune.brick_lk = 0;
     } else {
       for (int q = 0; q < 3; ++q) {
@@ -589,6 +603,8 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
       b->tune.brick_lj = lg[1];
       b->tune.brick_lk = lg[2];
     }
+  } else if (n == "ohx_brick_k_fastest") {
+    b->tune.brick_k_fastest = atoi(value) != 0;
   } else if (n == "ohx_lds_pad") {
     b->tune.lds_pad = atoi(value);
   } else if (n == "ohx_prefetch") {

@@ -69,11 +69,22 @@ __device__ __forceinline__ uint64_t tile_row(const TileShape& sh, uint64_t tile_
   const uint32_t bj = t % sh.nbj;
   const uint32_t bk = t / sh.nbj;
   const uint32_t l = (uint32_t)lane;
-  const uint32_t i = (bi << sh.li) + (l & ((1u << sh.li) - 1u));
-  const uint32_t j = (bj << sh.lj) + ((l >> sh.li) & ((1u << sh.lj) - 1u));
-  const uint32_t k = (bk << sh.lk) + (l >> (sh.li + sh.lj));
-  *valid = i < sh.im && j < sh.jm && k < sh.nk;
-  return (uint64_t)i + (uint64_t)sh.im * ((uint64_t)j + (uint64_t)sh.jm * (uint64_t)k);
+  uint32_t di, dj, dk;
+  if (sh.k_fastest) {
+    dk = l & ((1u << sh.lk) - 1u);
+    di = (l >> sh.lk) & ((1u << sh.li) - 1u);
+    dj = l >> (sh.lk + sh.li);
+  } else {
+    di = l & ((1u << sh.li) - 1u);
+    dj = (l >> sh.li) & ((1u << sh.lj) - 1u);
+    dk = l >> (sh.li + sh.lj);
+  }
+  const uint32_t i = (bi << sh.li) + di;
+  const uint32_t j = (bj << sh.lj) + dj;
+  const uint32_t k = sh.k_first + (bk << sh.lk) + dk;
+  const uint64_t m = (uint64_t)i + (uint64_t)sh.im * ((uint64_t)j + (uint64_t)sh.jm * (uint64_t)k);
+  *valid = i < sh.im && j < sh.jm && m >= sh.row0 && m - sh.row0 < sh.nrow;
+  return m - sh.row0;
 }
 
 // ------------------------------------------------------------------ tile fill
@@ -694,12 +705,14 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
   lds += (size_t)tune.lds_pad;
   hipError_t e = ensure_lds(kernel, lds);
   if (e != hipSuccess) return e;
-  // bricks when the caller named the grid and the rows are whole levels of it
-  const uint64_t plane = (uint64_t)(tune.grid_im > 0 ? tune.grid_im : 0) * (uint64_t)(tune.grid_jm > 0 ? tune.grid_jm : 0);
-  if (plane > 0 && tune.brick_li + tune.brick_lj + tune.brick_lk == 6 && a.nrow % plane == 0 &&
-      a.nrow / plane < (1u << 20))
-    a.shape.set_grid((uint32_t)tune.grid_im, (uint32_t)tune.grid_jm, (uint32_t)(a.nrow / plane), (uint32_t)tune.brick_li,
-                     (uint32_t)tune.brick_lj, (uint32_t)tune.brick_lk);
+  // bricks when the caller named the grid the rows come from
+  if (tune.grid_im > 0 && tune.grid_jm > 0 && a.nrow > 0 &&
+      (tune.brick_li < 0 || tune.brick_li + tune.brick_lj + tune.brick_lk == 6)) {
+    if (tune.brick_li < 0) a.shape.set_grid_auto((uint32_t)tune.grid_im, (uint32_t)tune.grid_jm, tune.grid_row0, a.nrow);
+    else a.shape.set_grid((uint32_t)tune.grid_im, (uint32_t)tune.grid_jm, tune.grid_row0, a.nrow, (uint32_t)tune.brick_li,
+                          (uint32_t)tune.brick_lj, (uint32_t)tune.brick_lk);
+    a.shape.k_fastest = (uint32_t)tune.brick_k_fastest;
+  }
   if (a.shape.ntiles(a.nrow) >= 0xFFFFFFFFull) a.shape = TileShape();   // tile_row numbers bricks in 32 bits
   const uint64_t ntiles = a.shape.ntiles(a.nrow);
   const int grid = tile_grid(kernel, lds, ntiles, num_cus);
@@ -781,9 +794,11 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
                                hipStream_t stream, const LaunchTuning& tune) {
   hipError_t e = ensure_lds(kernel, lds);
   if (e != hipSuccess) return e;
-  if (tune.brick_li + tune.brick_lj + tune.brick_lk == 6)
-    a.shape.set_grid((uint32_t)a.im, (uint32_t)a.jm, (uint32_t)(a.k2 - a.k1 + 1), (uint32_t)tune.brick_li,
-                     (uint32_t)tune.brick_lj, (uint32_t)tune.brick_lk);
+  if (tune.brick_li < 0) a.shape.set_grid_auto((uint32_t)a.im, (uint32_t)a.jm, 0, nrow);
+  else if (tune.brick_li + tune.brick_lj + tune.brick_lk == 6)
+    a.shape.set_grid((uint32_t)a.im, (uint32_t)a.jm, 0, nrow, (uint32_t)tune.brick_li, (uint32_t)tune.brick_lj,
+                     (uint32_t)tune.brick_lk);
+  a.shape.k_fastest = (uint32_t)tune.brick_k_fastest;
   if (a.shape.ntiles(nrow) >= 0xFFFFFFFFull) a.shape = TileShape();
   const uint64_t ntiles = a.shape.ntiles(nrow);
   const int grid = tile_grid(kernel, lds, ntiles, num_cus);

@@ -32,19 +32,42 @@ struct DeviceForest {
 // Which 64 rows a wave takes.  Without a grid (im == 0) tile t is rows 64t .. 64t+63.  With the
 // grid the rows were gathered from (m = i + im*(j + jm*k), OH_GridCompMod.F90:309-345) a tile is a
 // brick of 2^li x 2^lj x 2^lk neighbouring gridcells: neighbours in all three directions have
-// similar features, so the lanes of a wave share more tree nodes (fewer L1 tag look-ups per
-// gather) than 64 cells of one latitude line do.  Bricks overhang the grid where
-// an extent is not a multiple of the brick's; those lanes idle.
+// similar features, so the four lanes of a quad - the unit the L1 looks tags up for - and the
+// lanes of a wave share more tree nodes than 64 cells of one latitude line do.
+// The rows may be any contiguous range [row0, row0 + nrow) of the grid's rows (a rank's shard);
+// bricks overhang the range where an extent is not a multiple of the brick's; those lanes idle.
 struct TileShape {
-  uint32_t im = 0, jm = 0, nk = 0;
+  uint32_t im = 0, jm = 0;
+  uint32_t k_first = 0, nk = 0;         // levels the row range touches
+  uint64_t row0 = 0, nrow = 0;
   uint32_t li = 2, lj = 2, lk = 2;      // li + lj + lk == 6
   uint32_t nbi = 0, nbj = 0, nbk = 0;   // bricks along i, j, k
-  uint64_t ntiles(uint64_t nrow) const { return im ? (uint64_t)nbi * nbj * nbk : (nrow + 63) / 64; }
-  void set_grid(uint32_t im_, uint32_t jm_, uint32_t nk_, uint32_t li_, uint32_t lj_, uint32_t lk_) {
-    im = im_; jm = jm_; nk = nk_; li = li_; lj = lj_; lk = lk_;
+  uint32_t k_fastest = 0;               // lane order inside a brick: 0 = i, j, k; 1 = k, i, j
+  uint64_t ntiles(uint64_t nrow_) const { return im ? (uint64_t)nbi * nbj * nbk : (nrow_ + 63) / 64; }
+  // fraction of lanes that carry a row
+  double fill() const { return im ? (double)nrow / (64.0 * (double)ntiles(nrow)) : 1.0; }
+  void set_grid(uint32_t im_, uint32_t jm_, uint64_t row0_, uint64_t nrow_, uint32_t li_, uint32_t lj_, uint32_t lk_) {
+    im = im_; jm = jm_; row0 = row0_; nrow = nrow_; li = li_; lj = lj_; lk = lk_;
+    const uint64_t plane = (uint64_t)im * jm;
+    k_first = (uint32_t)(row0 / plane);
+    nk = (uint32_t)((row0 + nrow - 1) / plane) - k_first + 1;
     nbi = (im + (1u << li) - 1) >> li;
     nbj = (jm + (1u << lj) - 1) >> lj;
     nbk = (nk + (1u << lk) - 1) >> lk;
+  }
+  // The brick that wastes the fewest lanes, preferring the more compact one on a tie within a few
+  // percent (measured on the C360 step: 4x4x4 36.4 ms, 8x4x2 36.6 ms, 8x8x1 37.1 ms).
+  void set_grid_auto(uint32_t im_, uint32_t jm_, uint64_t row0_, uint64_t nrow_) {
+    static const uint32_t cand[3][3] = {{2, 2, 2}, {3, 2, 1}, {3, 3, 0}};
+    static const double speed[3] = {1.0, 0.994, 0.98};
+    double best = -1.0;
+    int pick = 0;
+    for (int q = 0; q < 3; ++q) {
+      set_grid(im_, jm_, row0_, nrow_, cand[q][0], cand[q][1], cand[q][2]);
+      const double score = fill() * speed[q];
+      if (score > best) best = score, pick = q;
+    }
+    set_grid(im_, jm_, row0_, nrow_, cand[pick][0], cand[pick][1], cand[pick][2]);
   }
 };
 
@@ -71,10 +94,13 @@ struct LaunchTuning {
   int xcd_remap = 1;
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
-  // rows API: the grid the rows were gathered from (XGBoosterSetParam "ohx_grid" = "im,jm"); used
-  // when the row count is a whole number of (im x jm) levels.  0 = unknown, tiles are 64 rows.
+  // rows API: the grid the rows were gathered from and the grid row the matrix starts at
+  // (XGBoosterSetParam "ohx_grid" = "im,jm[,row0]").  0 = unknown, tiles are 64 consecutive rows.
   int grid_im = 0, grid_jm = 0;
-  int brick_li = 2, brick_lj = 2, brick_lk = 2;   // log2 extents of a wave's brick; all 0 = no bricks
+  uint64_t grid_row0 = 0;
+  // log2 extents of a wave's brick; -1 = chosen per call (TileShape::set_grid_auto); all 0 = no bricks
+  int brick_li = -1, brick_lj = -1, brick_lk = -1;
+  int brick_k_fastest = 0;
 };
 
 // 27 SoA fields of the MAPL state (OH_GridCompMod.F90:313-339), device pointers.

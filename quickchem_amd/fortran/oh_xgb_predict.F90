@@ -223,6 +223,9 @@ contains
 
       crc = XGDMatrixCreateFromMat(xx_carr, xx_prediction_count, xx_param_count, xx_miss, xx_dmtrx)
       if (crc /= 0) then; call fail('Failed in XGDMatrixCreateFromMat_f', rc); return; end if
+      ! not in the reference: tell the library which grid the rows were gathered from (speed only)
+      crc = OHXDMatrixSetGrid(xx_dmtrx, int(icount, c_int), int(jcount, c_int), 0_c_int64_t)
+      if (crc /= 0) then; call fail('Failed in OHXDMatrixSetGrid', rc); return; end if
 
       crc = XGBoosterPredict(xx_bst, xx_dmtrx, xx_option_mask, xx_ntree_limit, xx_training, xx_pred_len, xx_cpred)
       if (crc /= 0) then; call fail('Failed in XGBoosterPredict_f', rc); return; end if

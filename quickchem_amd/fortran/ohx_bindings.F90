@@ -14,7 +14,7 @@ module ohx_bindings
 
    public :: XGDMatrixCreateFromMat, XGDMatrixFree, XGDMatrixNumRow, XGDMatrixNumCol
    public :: XGBoosterCreate, XGBoosterFree, XGBoosterLoadModel, XGBoosterSaveModel
-   public :: XGBoosterPredict, XGBoosterSetParam, OHXBoosterPredictFields
+   public :: XGBoosterPredict, XGBoosterSetParam, OHXBoosterPredictFields, OHXDMatrixSetGrid
    public :: ohx_last_error, ohx_c_string
 
    interface
@@ -115,6 +115,15 @@ module ohx_bindings
          real(c_float), value           :: ohscale
          type(c_ptr), value             :: oh_ml, margin
          integer(c_int)                 :: rc
+      end function
+
+      ! Optional hint: the DMatrix rows are rows row0.. of the (im,jm,*) gather (ohxgb.h); speed only.
+      function OHXDMatrixSetGrid(handle, im, jm, row0) bind(C, name="OHXDMatrixSetGrid") result(rc)
+         import :: c_int, c_ptr, c_int64_t
+         type(c_ptr), value        :: handle
+         integer(c_int), value     :: im, jm
+         integer(c_int64_t), value :: row0
+         integer(c_int)            :: rc
       end function
 
       function c_strlen(s) bind(C, name="strlen") result(n)

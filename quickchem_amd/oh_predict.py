@@ -121,6 +121,8 @@ class OHPredictor:
             xx_dmtrx = capi.DMatrix(xx_carr, XX_MISS, lib=self.lib)                         # :347
         except capi.OhxError as e:
             raise AssertFailure(f"Failed in XGDMatrixCreateFromMat_f: {e}")
+        if hasattr(self.lib, "OHXDMatrixSetGrid"):
+            xx_dmtrx.set_grid(icount, jcount, 0)         # not in the reference: layout hint, speed only
         try:
             xx_pred = self.xx_bst.predict(xx_dmtrx, option_mask=0, ntree_limit=0, training=0)   # :356
         except capi.OhxError as e:

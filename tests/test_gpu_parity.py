@@ -14,7 +14,7 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["wide", "packed1", "packed2", "packed4", "super1", "super2", "super4"]
+KERNELS = ["wide", "packed1", "packed2", "packed4", "super1", "super2", "super3", "super4", "super6"]
 
 
 @pytest.fixture(scope="module")
@@ -25,12 +25,14 @@ def torch_cuda():
     return torch
 
 
-def gpu_predict(image, rows, missing, kernel="auto", option_mask=0, ntree_limit=0, params=None):
+def gpu_predict(image, rows, missing, kernel="auto", option_mask=0, ntree_limit=0, params=None, grid=None):
     b = capi.Booster(model_buffer=image)
     b.set_param("ohx_kernel", kernel)
     for k, v in (params or {}).items():
         b.set_param(k, v)
     d = capi.DMatrix(rows, missing=missing)
+    if grid is not None:
+        d.set_grid(*grid)
     out = b.predict(d, option_mask=option_mask, ntree_limit=ntree_limit)
     d.free()
     b.free()
@@ -288,3 +290,39 @@ def test_oversized_trees_use_the_packed_fallback(torch_cuda):
     d = capi.DMatrix(rows, missing=synth.XX_MISS)
     assert np.array_equal(helpers.bits(b.predict(d)), helpers.bits(want))
     assert b.info()["packed"] == 1
+
+
+@pytest.mark.parametrize("shape", [(4, 4, 72), (12, 72, 5), (10, 7, 9), (37, 3, 6), (1, 1, 130), (130, 1, 1)])
+def test_grid_hint_changes_nothing_but_the_tiling(torch_cuda, shape, small_model):
+    """OHXDMatrixSetGrid: a wave takes a brick of neighbouring gridcells instead of 64 consecutive rows.
+    Same margins bit for bit - for grids that are not multiples of any brick, shards that start and end
+    inside a level, every brick shape, both lane orders, with and without missing values."""
+    im, jm, nk = shape
+    n = im * jm * nk
+    rows = synth.rows_cpu((im, jm, max(nk, 2)), 0, n) if im > 1 or jm > 1 else synth.rows_cpu((4, 4, 72), 0, n)
+    want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
+    for brick in ("auto", "4,4,4", "8,8,1", "8,4,2", "2,2,16", "64,1,1", "1,1,64", "0,0,0"):
+        for kf in ("0", "1"):
+            got = gpu_predict(small_model.image, rows, synth.XX_MISS, "super2", grid=(im, jm, 0),
+                              params={"ohx_brick": brick, "ohx_brick_k_fastest": kf})
+            assert np.array_equal(helpers.bits(got), helpers.bits(want)), (brick, kf)
+    # a rank's shard: rows [r0, r0 + m) of the grid, starting and ending inside a level
+    plane = im * jm
+    for r0, m in ((plane // 3, n - plane // 3 - plane // 2), (0, max(1, plane // 2)), (n - 1, 1)):
+        if m < 1 or r0 + m > n:
+            continue
+        for kernel in ("super2", "super3", "packed2"):
+            got = gpu_predict(small_model.image, rows[r0:r0 + m], synth.XX_MISS, kernel, grid=(im, jm, r0))
+            assert np.array_equal(helpers.bits(got), helpers.bits(want[r0:r0 + m])), (r0, m, kernel)
+    holes = with_missing(rows, 0.01)
+    got = gpu_predict(small_model.image, holes, synth.XX_MISS, "super2", grid=(im, jm, 0))
+    assert np.array_equal(helpers.bits(got), helpers.bits(helpers.oracle_predict(small_model.image, holes, synth.XX_MISS)))
+
+
+def test_grid_hint_is_validated(torch_cuda):
+    d = capi.DMatrix(np.zeros((4, 27), np.float32), missing=synth.XX_MISS)
+    for bad in ((-1, 4, 0), (4, 0, 0), (0, 4, 0)):
+        with pytest.raises(capi.OhxError):
+            d.set_grid(*bad)
+    d.set_grid(0, 0, 0)
+    d.free()
