@@ -381,7 +381,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.grid, args.kernel, info["num_nodes"])
-                         if (world == 1 and not args.shuffle and not args.missing_ppm and not args.param) else None,
+                         if (world == 1 and use_grid and not args.shuffle and not args.missing_ppm and not args.param) else None,
                          "kernel": "predict_rows_tile_kernel<2,2>", "kernel_ms": kernel_s * 1e3,
                          "per": "step = the train of launches of one pass over the batch",
                          "launches_per_step": launches_per_step,

@@ -23,6 +23,7 @@ def main():
     for rep in range(3):
         t0 = time.perf_counter()
         d = capi.DMatrix(rows, missing=synth.XX_MISS)
+        d.set_grid(grid[0], grid[1], 3 * n)      # as the drop-in predict_OH_with_XGB does (speed only)
         t1 = time.perf_counter()
         p = b.predict(d)
         t2 = time.perf_counter()
