@@ -119,7 +119,7 @@ int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong nc
  * m = (i-1) + im*((j-1) + jm*(k-k1)) that predict_OH_with_XGB builds
  * (OH_GridCompMod.F90:309-345); row0 > 0 for a rank's contiguous shard.  Predictions do not
  * change.  The kernels then give each wavefront a brick of 4x4x4 (or 8x4x2, 8x8x1) neighbouring
- * gridcells instead of 64 consecutive rows, which measures 1.27x faster on C360 L72 because
+ * gridcells instead of 64 consecutive rows, which measures 1.15x faster on C360 L72 because
  * neighbours in all three directions walk the same tree nodes.  im = jm = 0 withdraws the hint. */
 int OHXDMatrixSetGrid(DMatrixHandle handle, int im, int jm, bst_ulong row0);
 
@@ -163,8 +163,9 @@ int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fie
  *   PL_BST = (PLE_BST(k-1)+PLE_BST(k))*0.5                               (:1488)
  *   the k-slab, predict_OH_with_XGB, OH_ML *= OHscale                    (:1559-1569)
  *   OH = PL_MOD > TROPP ? OH_ML : default_OH ; OH = (OH*NDWET_MOD)*1.0e-6   (:1579-1595)
- * What stays with the caller: the choice of import per OH_data_source, LAT in
- * degrees, and the local-noon SZA (:401-466; 2-D, libm-bound).
+ * What stays with the caller: the choice of import per OH_data_source.  LAT in degrees and the
+ * local-noon SZA are 2-D inputs of the struct; OHXSolarGeometry below computes them the reference's
+ * way for a caller who wants that on the GPU too.
  * All arrays are Fortran order: 3-D (im,jm,km), edge fields (im,jm,0:km), 2-D
  * (im,jm).  MAPL's constants are passed in, not restated.  Host form stages
  * through HBM and returns when the outputs are complete; device form takes device
@@ -195,6 +196,20 @@ typedef struct OHXRun1Args {
 
 int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args);
 int OHXBoosterRun1Device(BoosterHandle handle, const OHXRun1Args* args, void* stream);
+
+/* The solar geometry of OH Run1.  OHXJulianDay: JulianDay(nymd) with the reference's leap_year
+ * (OH_GridCompMod.F90:1905-1970; host integer arithmetic).  OHXSolarGeometry: latarr =
+ * LATS*MAPL_RADIANS_TO_DEGREES (:1444) and sza_noon = computeSolarZenithAngle_LocalNoon(jday, LATS,
+ * LONS) (:401-466, 1481-1482) for (im,jm) arrays in radians; either output may be NULL.  float32 in
+ * the reference's order of evaluation; sin/asin/cos/acos are the device library's, so the result
+ * agrees with a host run to a few ulp of cos(zenith) - which acos turns into up to ~0.05 degree
+ * where the sun is overhead.  SZA feeds tree splits: a caller that needs OH bit-identical to a CPU
+ * run passes its own sza to OHXBoosterRun1 instead. */
+int OHXJulianDay(int nymd, int* jday);
+int OHXSolarGeometry(int jday, const float* lats, const float* lons, int im, int jm, float degrees_to_radians,
+                     float radians_to_degrees, float* lat_deg, float* sza_noon);
+int OHXSolarGeometryDevice(int jday, const float* d_lats, const float* d_lons, int im, int jm, float degrees_to_radians,
+                           float radians_to_degrees, float* d_lat_deg, float* d_sza_noon, void* stream);
 
 /* Model facts for roofline accounting: info[0] trees, [1] nodes in the model,
  * [2] node slots in HBM, [3] bytes of the node array the selected kernel reads,

@@ -456,6 +456,48 @@ ORACLE_EXPORT int XGBoosterSetParam(void* h, const char* name, const char* value
   return 0;
 }
 
+/* OH Run1's solar geometry, restated from OH_GridComp/OH_GridCompMod.F90:1905-1970 (JulianDay,
+ * leap_year), :1444 (latarr) and :401-466 (computeSolarZenithAngle_LocalNoon): float32, the
+ * reference's order of evaluation, the host libm's sinf/asinf/cosf/acosf. */
+ORACLE_EXPORT int oracle_julian_day(int nymd) {
+  static const int days[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+  const int ny = nymd / 10000, mm = (nymd % 10000) / 100, dd = nymd % 100;
+  int leap = 0;
+  if (ny >= 0) {                                               /* :1957 */
+    if (ny % 100 == 0 && ny % 400 == 0) leap = 1;              /* :1958 */
+    else if (ny % 4 == 0 && ny % 100 != 0) leap = 1;           /* :1960 */
+  }
+  int ds = dd;                                                 /* :1923 */
+  if (mm != 1)
+    for (int m = 1; m <= mm - 1 && m <= 12; ++m) ds += (m == 2 && leap) ? 29 : days[m - 1];   /* :1925-1932 */
+  return ds;
+}
+
+ORACLE_EXPORT int oracle_solar_geometry(int jday, const float* lats, const float* lons, int im, int jm, float deg2rad,
+                                        float rad2deg, float* lat_deg, float* sza_noon) {
+  const size_t plane = (size_t)im * (size_t)jm;
+  const float sindec = 0.3978f * sinf(0.9863f * ((float)jday - 80.0f) * deg2rad);   /* :427 */
+  const float soldek = asinf(sindec);                                                /* :428 */
+  const float cosdec = cosf(soldek);                                                 /* :429 */
+  for (size_t m = 0; m < plane; ++m) {
+    if (lat_deg) lat_deg[m] = lats[m] * rad2deg;                                     /* :1444 */
+    if (!sza_noon) continue;
+    const float sinlat = sinf(lats[m]);                                              /* :430 */
+    const float sollat = asinf(sinlat);                                              /* :431 */
+    const float coslat = cosf(sollat);                                               /* :432 */
+    float mylon = lons[m] * rad2deg;                                                 /* :439 */
+    if (mylon > 180.0f) mylon = mylon - 360.0f;                                      /* :441 */
+    if (mylon < -180.0f) mylon = mylon + 360.0f;                                     /* :442 */
+    const float tau = 12.0f + (mylon / -180.0f) * 12.0f;                             /* :443 */
+    const float loct = ((tau * 15.0f) - 180.0f) * deg2rad + lons[m];                 /* :445 */
+    float cosz = cosdec * coslat * cosf(loct) + sindec * sinlat;                     /* :446 */
+    cosz = fminf(1.0f, cosz);                                                        /* :459 */
+    cosz = fmaxf(-1.0f, cosz);                                                       /* :460 */
+    sza_noon[m] = acosf(cosz) * rad2deg;                                             /* :462 */
+  }
+  return 0;
+}
+
 /* The product's layout hint (include/ohxgb.h); predictions do not depend on it, so the oracle
  * only checks the arguments. */
 ORACLE_EXPORT int OHXDMatrixSetGrid(void* dmat, int im, int jm, uint64_t row0) {

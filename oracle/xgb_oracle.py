@@ -360,3 +360,34 @@ def run1(model: OracleModel, st: dict, dynamic_k_range: bool, tropp_min: float =
     ohv = np.where(pl_mod > np.asarray(st["tropp_mod"], dtype=f32)[:, :, None], oh_ml, st["default_oh"]).astype(f32)
     oh = ((ohv * ndwet).astype(f32) * f32(1.0e-6)).astype(f32)                              # :1595
     return {"oh": oh, "oh_boost": oh_ml, "ndwet": ndwet, "k1": k1, "k2": k2, "fields": fields, "margin": margin}
+
+
+# ---- OH Run1's solar geometry (OH_GridCompMod.F90:401-466, 1444, 1905-1970) ----
+
+def julian_day(nymd: int) -> int:
+    ny, mm, dd = nymd // 10000, (nymd % 10000) // 100, nymd % 100
+    leap = ny >= 0 and ((ny % 100 == 0 and ny % 400 == 0) or (ny % 4 == 0 and ny % 100 != 0))   # :1957-1964
+    days = [31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31]
+    ds = dd
+    for m in range(1, mm):                                                                   # :1925-1932
+        ds += 29 if (m == 2 and leap) else days[m - 1]
+    return ds
+
+
+def solar_geometry(jday: int, lats, lons, deg2rad, rad2deg):
+    """(lat_deg, sza_noon) in float32, the reference's order of evaluation, numpy's float32 sin/cos/arcsin/arccos."""
+    f = np.float32
+    lats, lons = np.asarray(lats, dtype=f), np.asarray(lons, dtype=f)
+    deg2rad, rad2deg = f(deg2rad), f(rad2deg)
+    sindec = f(0.3978) * np.sin(f(0.9863) * (f(jday) - f(80.0)) * deg2rad, dtype=f)          # :427
+    cosdec = np.cos(np.arcsin(sindec, dtype=f), dtype=f)                                      # :428-429
+    sinlat = np.sin(lats, dtype=f)                                                            # :430
+    coslat = np.cos(np.arcsin(sinlat, dtype=f), dtype=f)                                      # :431-432
+    mylon = lons * rad2deg                                                                    # :439
+    mylon = np.where(mylon > f(180.0), mylon - f(360.0), mylon)                               # :441
+    mylon = np.where(mylon < f(-180.0), mylon + f(360.0), mylon)                              # :442
+    tau = f(12.0) + (mylon / f(-180.0)) * f(12.0)                                             # :443
+    loct = ((tau * f(15.0)) - f(180.0)) * deg2rad + lons                                      # :445
+    cosz = cosdec * coslat * np.cos(loct, dtype=f) + sindec * sinlat                          # :446
+    cosz = np.maximum(f(-1.0), np.minimum(f(1.0), cosz))                                      # :459-460
+    return lats * rad2deg, np.arccos(cosz, dtype=f) * rad2deg                                 # :1444, :462

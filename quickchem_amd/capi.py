@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device",
-    "OHXBoosterGetInfo", "OHXSynthRowsDevice",
+    "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXSynthRowsDevice",
     "OHXSynthFieldDevice", "OHXInjectMissingDevice",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
@@ -103,6 +103,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                                                   i32, i32, f32, i32, f32, vp, vp, vp]
     lib.OHXBoosterRun1.argtypes = [vp, C.POINTER(OHXRun1Args)]
     lib.OHXBoosterRun1Device.argtypes = [vp, C.POINTER(OHXRun1Args), vp]
+    lib.OHXJulianDay.argtypes = [i32, C.POINTER(i32)]
+    lib.OHXSolarGeometry.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp]
+    lib.OHXSolarGeometryDevice.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp, vp]
     lib.OHXBoosterGetInfo.argtypes = [vp, C.POINTER(u64)]
     lib.OHXSynthRowsDevice.argtypes = [u32, i32, i32, i32, u64, u64, vp, vp]
     lib.OHXSynthFieldDevice.argtypes = [u32, i32, i32, i32, i32, vp, vp]
@@ -119,6 +122,31 @@ def check(lib: C.CDLL, rc: int) -> None:
 
 def _as_f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# MAPL_DEGREES_TO_RADIANS / MAPL_RADIANS_TO_DEGREES as MAPL defines them (real32 of pi / 180 and its inverse)
+DEG2RAD = np.float32(np.float32(np.pi) / np.float32(180.0))
+RAD2DEG = np.float32(np.float32(180.0) / np.float32(np.pi))
+
+
+def julian_day(nymd: int, lib: Optional[C.CDLL] = None) -> int:
+    """OHXJulianDay: day of year of a yyyymmdd date (OH_GridCompMod.F90:1905-1936)."""
+    lib = lib or load_library()
+    out = C.c_int32()
+    check(lib, lib.OHXJulianDay(nymd, C.byref(out)))
+    return out.value
+
+
+def solar_geometry(jday: int, lats, lons, deg2rad=DEG2RAD, rad2deg=RAD2DEG, lib: Optional[C.CDLL] = None):
+    """OHXSolarGeometry on [i,j]-indexed (im, jm) arrays in radians -> (lat_deg, sza_noon), same indexing."""
+    lib = lib or load_library()
+    la = np.ascontiguousarray(np.asarray(lats, dtype=np.float32).T)
+    lo = np.ascontiguousarray(np.asarray(lons, dtype=np.float32).T)
+    jm, im = la.shape
+    lat_deg, sza = np.empty_like(la), np.empty_like(la)
+    check(lib, lib.OHXSolarGeometry(jday, la.ctypes.data, lo.ctypes.data, im, jm, float(deg2rad), float(rad2deg),
+                                    lat_deg.ctypes.data, sza.ctypes.data))
+    return lat_deg.T, sza.T
 
 
 class DMatrix:

@@ -875,6 +875,65 @@ int OHXBoosterRun1Device(BoosterHandle handle, const OHXRun1Args* args, void* st
   API_END();
 }
 
+int OHXJulianDay(int nymd, int* jday) {
+  API_BEGIN();
+  if (jday == nullptr) throw OhxError("OHXJulianDay: jday is NULL");
+  static const int days[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+  const int ny = nymd / 10000, mm = (nymd % 10000) / 100, dd = nymd % 100;
+  // leap_year (:1940-1970): no leap years before year 0
+  const bool leap = ny >= 0 && ((ny % 100 == 0 && ny % 400 == 0) || (ny % 4 == 0 && ny % 100 != 0));
+  int ds = dd;
+  for (int m = 1; m < mm && m <= 12; ++m) ds += (m == 2 && leap) ? 29 : days[m - 1];
+  *jday = ds;
+  API_END();
+}
+
+int OHXSolarGeometryDevice(int jday, const float* d_lats, const float* d_lons, int im, int jm, float deg2rad,
+                           float rad2deg, float* d_lat_deg, float* d_sza_noon, void* stream) {
+  API_BEGIN();
+  if (im < 0 || jm < 0) throw OhxError("OHXSolarGeometry: im and jm must not be negative");
+  if ((size_t)im * (size_t)jm != 0 && (d_lats == nullptr || (d_sza_noon != nullptr && d_lons == nullptr)))
+    throw OhxError("OHXSolarGeometry: LATS (and LONS, for the zenith angle) must not be NULL");
+  use_device(-1);
+  SolarArgs a;
+  a.im = im; a.jm = jm; a.jday = jday;
+  a.deg2rad = deg2rad; a.rad2deg = rad2deg;
+  a.lats = d_lats; a.lons = d_lons;
+  a.lat_deg = d_lat_deg; a.sza_noon = d_sza_noon;
+  HIP_CHECK(launch_solar_geometry(a, static_cast<hipStream_t>(stream)));
+  API_END();
+}
+
+int OHXSolarGeometry(int jday, const float* lats, const float* lons, int im, int jm, float deg2rad, float rad2deg,
+                     float* lat_deg, float* sza_noon) {
+  API_BEGIN();
+  if (im < 0 || jm < 0) throw OhxError("OHXSolarGeometry: im and jm must not be negative");
+  const size_t plane = (size_t)im * (size_t)jm;
+  if (plane == 0) return 0;
+  if (lats == nullptr || (sza_noon != nullptr && lons == nullptr))
+    throw OhxError("OHXSolarGeometry: LATS (and LONS, for the zenith angle) must not be NULL");
+  use_device(-1);
+  DevBuf<float> d_lats, d_lons, d_lat, d_sza;
+  d_lats.ensure(plane);
+  HIP_CHECK(hipMemcpy(d_lats.p, lats, plane * sizeof(float), hipMemcpyHostToDevice));
+  if (sza_noon) {
+    d_lons.ensure(plane);
+    HIP_CHECK(hipMemcpy(d_lons.p, lons, plane * sizeof(float), hipMemcpyHostToDevice));
+    d_sza.ensure(plane);
+  }
+  if (lat_deg) d_lat.ensure(plane);
+  SolarArgs a;
+  a.im = im; a.jm = jm; a.jday = jday;
+  a.deg2rad = deg2rad; a.rad2deg = rad2deg;
+  a.lats = d_lats.p; a.lons = d_lons.p;
+  a.lat_deg = lat_deg ? d_lat.p : nullptr;
+  a.sza_noon = sza_noon ? d_sza.p : nullptr;
+  HIP_CHECK(launch_solar_geometry(a, nullptr));
+  if (lat_deg) HIP_CHECK(hipMemcpy(lat_deg, d_lat.p, plane * sizeof(float), hipMemcpyDeviceToHost));
+  if (sza_noon) HIP_CHECK(hipMemcpy(sza_noon, d_sza.p, plane * sizeof(float), hipMemcpyDeviceToHost));
+  API_END();
+}
+
 int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   API_BEGIN();
   BoosterObj* b = as_booster(handle);

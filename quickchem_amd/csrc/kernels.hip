@@ -611,6 +611,37 @@ __global__ __launch_bounds__(kBlock) void post_process_kernel(PostArgs a) {
   }
 }
 
+// latarr = LATS*MAPL_RADIANS_TO_DEGREES (:1444) and computeSolarZenithAngle_LocalNoon (:401-466), the
+// reference's float32 expressions in its order of evaluation.  sin/asin/cos/acos are the device
+// library's: results agree with a host libm to a few ulp, and acos turns one ulp of cosz near +-1
+// into hundredths of a degree - which is why the library never computes SZA behind the caller's back.
+__global__ __launch_bounds__(kBlock) void solar_geometry_kernel(SolarArgs a) {
+#pragma clang fp contract(off)
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const float sindec = 0.3978f * sinf(0.9863f * ((float)a.jday - 80.0f) * a.deg2rad);
+  const float soldek = asinf(sindec);
+  const float cosdec = cosf(soldek);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < plane; m += stride) {
+    const float lat = a.lats[m];
+    if (a.lat_deg) a.lat_deg[m] = lat * a.rad2deg;
+    if (!a.sza_noon) continue;
+    const float lon = a.lons[m];
+    const float sinlat = sinf(lat);
+    const float sollat = asinf(sinlat);
+    const float coslat = cosf(sollat);
+    float mylon = lon * a.rad2deg;
+    if (mylon > 180.0f) mylon = mylon - 360.0f;
+    if (mylon < -180.0f) mylon = mylon + 360.0f;
+    const float tau = 12.0f + (mylon / -180.0f) * 12.0f;
+    const float loct = ((tau * 15.0f) - 180.0f) * a.deg2rad + lon;
+    float cosz = cosdec * coslat * cosf(loct) + sindec * sinlat;
+    cosz = fminf(1.0f, cosz);
+    cosz = fmaxf(-1.0f, cosz);
+    a.sza_noon[m] = acosf(cosz) * a.rad2deg;
+  }
+}
+
 // ------------------------------------------------------------------ synthetic inputs
 
 __global__ __launch_bounds__(kBlock) void synth_rows_kernel(uint32_t seed, int im, int jm, int km, uint64_t row_begin,
@@ -855,6 +886,13 @@ hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_
   const uint64_t cols_per_block = (uint64_t)kWavesPerBlock * kWave;
   hipLaunchKernelGGL(feature_column_sums_kernel, dim3((unsigned)((plane + cols_per_block - 1) / cols_per_block), 3),
                      dim3(kBlock), lds, stream, a, (const float*)aod_scratch);
+  return hipGetLastError();
+}
+
+hipError_t launch_solar_geometry(const SolarArgs& a, hipStream_t stream) {
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  if (plane == 0) return hipSuccess;
+  hipLaunchKernelGGL(solar_geometry_kernel, dim3(grid_for(plane, 256, 8)), dim3(kBlock), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -149,6 +149,15 @@ struct PostArgs {
   float *oh = nullptr, *ndwet = nullptr;
 };
 
+// OH Run1's solar geometry (OH_GridCompMod.F90:401-466, 1444): 2-D, device pointers.
+struct SolarArgs {
+  int im = 0, jm = 0, jday = 0;
+  float deg2rad = 0, rad2deg = 0;          // MAPL_DEGREES_TO_RADIANS, MAPL_RADIANS_TO_DEGREES
+  const float *lats = nullptr, *lons = nullptr;   // radians
+  float *lat_deg = nullptr, *sza_noon = nullptr;  // either may be null
+};
+hipError_t launch_solar_geometry(const SolarArgs& a, hipStream_t stream);
+
 hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_t stream);  // aod_scratch: (im,jm,km)
 hipError_t launch_k_slab(const SlabArgs& a, hipStream_t stream);
 hipError_t launch_post_process(const PostArgs& a, hipStream_t stream);

@@ -95,3 +95,66 @@ def test_run1_gpu_error_paths(small_model):
     st3["no2"][1, 1, 11] = np.inf
     with pytest.raises(capi.OhxError, match="inf"):
         b.run1(st3, dynamic_k_range=True)
+
+
+# ---- solar geometry (OH_GridCompMod.F90:401-466, 1444, 1905-1970) ----
+
+JDAY_CASES = {20240101: 1, 20240229: 60, 20240301: 61, 20230301: 60, 21000301: 60, 20001231: 366, 19001231: 365,
+              20230704: 185, 20241231: 366, 20230131: 31}   # worked out by hand from the calendar
+
+
+def _lonlat(im=72, jm=37):
+    lon = np.linspace(-np.pi, np.pi, im, endpoint=False, dtype=np.float32) + np.float32(0.01)
+    lat = np.linspace(-np.pi / 2, np.pi / 2, jm, dtype=np.float32)
+    lons, lats = np.meshgrid(lon, lat, indexing="ij")
+    # also longitudes on the 0..2pi convention, which the reference folds back (:441-442)
+    lons[::3, :] += np.float32(2 * np.pi)
+    return lats.astype(np.float32), lons.astype(np.float32)
+
+
+def _sza_tolerance(jday, lats):
+    """acos near +-1: one ulp of cosz is worth sqrt(2*6e-8) rad = 0.02 degree; elsewhere 1e-3 degree."""
+    dec = np.degrees(np.arcsin(0.3978 * np.sin(0.9863 * (jday - 80.0) * np.pi / 180.0)))
+    near = np.abs(np.degrees(lats.astype(np.float64)) - dec) < 1.0
+    return np.where(near, 0.05, 2e-3)
+
+
+def test_solar_geometry_oracles_agree_and_match_the_closed_form(oracle_lib):
+    import ctypes as C
+    for nymd, want in JDAY_CASES.items():
+        assert O.julian_day(nymd) == want and oracle_lib.oracle_julian_day(nymd) == want, nymd
+    lats, lons = _lonlat()
+    for jday in (1, 80, 172, 266, 355, 366):
+        lat_np, sza_np = O.solar_geometry(jday, lats, lons, capi.DEG2RAD, capi.RAD2DEG)
+        la, lo = np.ascontiguousarray(lats.T), np.ascontiguousarray(lons.T)
+        lat_c, sza_c = np.empty_like(la), np.empty_like(la)
+        oracle_lib.oracle_solar_geometry.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                                     C.c_float, C.c_void_p, C.c_void_p]
+        assert oracle_lib.oracle_solar_geometry(jday, la.ctypes.data, lo.ctypes.data, lats.shape[0], lats.shape[1],
+                                                float(capi.DEG2RAD), float(capi.RAD2DEG), lat_c.ctypes.data,
+                                                sza_c.ctypes.data) == 0
+        assert np.array_equal(lat_c.T, lat_np)                       # one float32 multiply
+        tol = _sza_tolerance(jday, lats)
+        assert (np.abs(sza_c.T.astype(np.float64) - sza_np) <= tol).all()
+        # local noon: the hour angle is zero, so the zenith angle is |latitude - declination|
+        dec = np.degrees(np.arcsin(0.3978 * np.sin(0.9863 * (jday - 80.0) * np.pi / 180.0)))
+        closed = np.abs(np.degrees(lats.astype(np.float64)) - dec)
+        assert (np.abs(sza_np - closed) <= 0.06).all()
+
+
+@pytest.mark.gpu
+def test_solar_geometry_gpu_against_the_oracle():
+    """Tolerance, stated: float32 trig of the device library against the host's - 2e-3 degree, 0.05 degree
+    within one degree of the subsolar latitude (acos near 1); LAT in degrees is one multiply, bit-exact."""
+    for nymd, want in JDAY_CASES.items():
+        assert capi.julian_day(nymd) == want
+    lats, lons = _lonlat(144, 91)
+    for jday in (1, 80, 172, 266, 366):
+        lat_deg, sza = capi.solar_geometry(jday, lats, lons)
+        lat_np, sza_np = O.solar_geometry(jday, lats, lons, capi.DEG2RAD, capi.RAD2DEG)
+        assert np.array_equal(lat_deg, lat_np)
+        assert (np.abs(sza.astype(np.float64) - sza_np) <= _sza_tolerance(jday, lats)).all()
+        assert sza.min() >= 0.0 and sza.max() <= 180.0
+    lib = capi.load_library()
+    with pytest.raises(capi.OhxError, match="LATS"):
+        capi.check(lib, lib.OHXSolarGeometry(80, None, None, 4, 4, 0.0, 0.0, None, None))
