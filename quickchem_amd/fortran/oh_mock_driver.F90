@@ -30,7 +30,7 @@ program oh_mock_driver
    integer :: f, slot2(27), slot3(27)
 
    if (command_argument_count() < 3) then
-      print *, 'usage: oh_mock_driver <state.bin> <model> <out.bin> [compat|fused] [ncalls]'
+      print *, 'usage: oh_mock_driver <state.bin> <model or %m2 pattern> <out.bin> [compat|fused] [ncalls] [reference|by_name]'
       stop 2
    end if
    call get_command_argument(1, state_file)
@@ -42,6 +42,12 @@ program oh_mock_driver
    if (command_argument_count() >= 5) then
       call get_command_argument(5, arg)
       read(arg, *) ncalls
+   end if
+   !  call number `it` is dated 2024-<it>-01: a month-templated model name (OH_instance_OH.rc:20)
+   !  rolls over between calls, and the policy says what that does
+   if (command_argument_count() >= 6) then
+      call get_command_argument(6, arg)
+      if (trim(arg) == 'by_name') call oh_xgb_set_model_policy(OH_XGB_POLICY_BY_NAME)
    end if
 
    open(newunit=u, file=trim(state_file), access='stream', form='unformatted', status='old', action='read')
@@ -99,9 +105,11 @@ program oh_mock_driver
    do it = 1, ncalls
       OH_ML(:,:,:) = 0.0                       ! OH_GridCompMod.F90:1559
       if (trim(mode) == 'fused') then
-         call predict_OH_with_XGB_fused(trim(model_file), im, jm, km, dyn /= 0, tropp_min, pl, tropp, bb, ohscale, OH_ML, rc)
+         call predict_OH_with_XGB_fused(oh_xgb_fill_template(model_file, 20240001 + 100*it, 0), im, jm, km, &
+                                        dyn /= 0, tropp_min, pl, tropp, bb, ohscale, OH_ML, rc)
       else
-         call predict_OH_with_XGB(trim(model_file), im, jm, km, dyn /= 0, tropp_min, pl, tropp, bb, OH_ML, rc)
+         call predict_OH_with_XGB(oh_xgb_fill_template(model_file, 20240001 + 100*it, 0), im, jm, km, &
+                                  dyn /= 0, tropp_min, pl, tropp, bb, OH_ML, rc)
          if (rc == OH_XGB_SUCCESS) OH_ML(:,:,:) = OH_ML(:,:,:) * ohscale      ! :1569
       end if
       if (rc /= OH_XGB_SUCCESS) exit
@@ -121,6 +129,7 @@ program oh_mock_driver
    write(u) int(rc, c_int32_t), int(k1, c_int32_t), int(k2, c_int32_t)
    write(u) OH_ML
    write(u) seconds
+   write(u) int(oh_xgb_resident_models(), c_int32_t)
    close(u)
    if (rc /= OH_XGB_SUCCESS) stop 1
 end program oh_mock_driver

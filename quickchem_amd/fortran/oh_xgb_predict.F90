@@ -20,6 +20,13 @@ module oh_xgb_predict
 
    public :: OH_BOOST_INPUT_DATA, predict_OH_with_XGB, predict_OH_with_XGB_fused
    public :: oh_xgb_k_slab, oh_xgb_reset, oh_xgb_error_text
+   public :: oh_xgb_set_model_policy, oh_xgb_fill_template, oh_xgb_resident_models
+
+   !  Which booster a call uses when the file name changes between calls.  The reference keeps the
+   !  booster of the FIRST call for the life of the process and ignores later names, although the
+   !  name is month-templated (first_time, :209,269; OH_instance_OH.rc:20).
+   integer, parameter, public :: OH_XGB_POLICY_REFERENCE = 0   ! as the reference: load once
+   integer, parameter, public :: OH_XGB_POLICY_BY_NAME   = 1   ! one resident booster per file name
 
    integer, parameter, public :: OH_XGB_SUCCESS = 0
    integer, parameter, public :: OH_XGB_FAILURE = 1
@@ -63,6 +70,14 @@ module oh_xgb_predict
    logical, save     :: first_time = .true.
    character(len=512), save :: last_error = ''
 
+   !  OH_XGB_POLICY_BY_NAME: the twelve monthly boosters stay resident in HBM (46 MB each for the
+   !  100-tree model; 288 GB per GPU), a month roll-over is a table look-up
+   integer, parameter :: max_resident = 16
+   integer, save :: model_policy = OH_XGB_POLICY_REFERENCE
+   integer, save :: n_resident = 0
+   character(len=1024), save :: resident_name(max_resident) = ''
+   type(c_ptr), save :: resident_bst(max_resident) = c_null_ptr
+
 contains
 
    function oh_xgb_error_text() result(msg)
@@ -70,12 +85,88 @@ contains
       msg = trim(last_error)
    end function
 
-   !  Forget the process-wide booster (the reference never frees it, :389-392)
+   !  Forget the process-wide booster(s) (the reference never frees it, :389-392)
    subroutine oh_xgb_reset()
       integer(c_int) :: rc
-      if (c_associated(xx_bst)) rc = XGBoosterFree(xx_bst)
+      integer :: q
+      logical :: listed
+      listed = .false.
+      do q = 1, n_resident
+         if (c_associated(resident_bst(q), xx_bst)) listed = .true.
+         if (c_associated(resident_bst(q))) rc = XGBoosterFree(resident_bst(q))
+         resident_bst(q) = c_null_ptr
+         resident_name(q) = ''
+      end do
+      n_resident = 0
+      if (c_associated(xx_bst) .and. .not. listed) rc = XGBoosterFree(xx_bst)
       xx_bst = c_null_ptr
       first_time = .true.
+   end subroutine
+
+   subroutine oh_xgb_set_model_policy(policy)
+      integer, intent(in) :: policy
+      model_policy = policy
+   end subroutine
+
+   integer function oh_xgb_resident_models()
+      oh_xgb_resident_models = n_resident
+   end function
+
+   !  The GrADS-style tokens MAPL's fill_grads_template expands in XGBoostFile
+   !  (OH_GridCompMod.F90:1187, OH_instance_OH.rc:20): %y4 %m2 %d2 %h2 %n2
+   function oh_xgb_fill_template(pattern, nymd, nhms) result(name)
+      character(len=*), intent(in) :: pattern
+      integer, intent(in) :: nymd, nhms
+      character(len=:), allocatable :: name
+      character(len=4) :: buf
+      integer :: p
+      name = trim(pattern)
+      do
+         p = index(name, '%')
+         if (p == 0 .or. p + 2 > len(name)) exit
+         select case (name(p+1:p+2))
+         case ('y4'); write(buf, '(i4.4)') nymd / 10000
+            name = name(:p-1)//buf(1:4)//name(p+3:)
+         case ('m2'); write(buf, '(i2.2)') mod(nymd, 10000) / 100
+            name = name(:p-1)//buf(1:2)//name(p+3:)
+         case ('d2'); write(buf, '(i2.2)') mod(nymd, 100)
+            name = name(:p-1)//buf(1:2)//name(p+3:)
+         case ('h2'); write(buf, '(i2.2)') nhms / 10000
+            name = name(:p-1)//buf(1:2)//name(p+3:)
+         case ('n2'); write(buf, '(i2.2)') mod(nhms, 10000) / 100
+            name = name(:p-1)//buf(1:2)//name(p+3:)
+         case default
+            exit          ! an unknown token is left as it is
+         end select
+      end do
+   end function
+
+   !  Select (loading it on first sight) the booster for this call
+   subroutine select_booster(xgb_fname, rc)
+      character(len=*), intent(in) :: xgb_fname
+      integer, intent(out) :: rc
+      integer :: q
+      rc = OH_XGB_SUCCESS
+      if (model_policy == OH_XGB_POLICY_REFERENCE) then
+         if (first_time) call one_time_setup(xgb_fname, rc)
+         return
+      end if
+      do q = 1, n_resident
+         if (trim(resident_name(q)) == trim(xgb_fname)) then
+            xx_bst = resident_bst(q)
+            return
+         end if
+      end do
+      if (n_resident == max_resident) then
+         last_error = 'more resident boosters than oh_xgb_predict keeps (16)'
+         rc = OH_XGB_FAILURE
+         return
+      end if
+      call one_time_setup(xgb_fname, rc)
+      if (rc /= OH_XGB_SUCCESS) return
+      n_resident = n_resident + 1
+      resident_name(n_resident) = trim(xgb_fname)
+      resident_bst(n_resident) = xx_bst
    end subroutine
 
    subroutine fail(what, rc)
@@ -173,8 +264,8 @@ contains
       xx_ntree_limit = 0      ! :232
       xx_training    = 0      ! :235
 
-      if (first_time) then
-         call one_time_setup(xgb_fname, rc)
+      if (first_time .or. model_policy /= OH_XGB_POLICY_REFERENCE) then
+         call select_booster(xgb_fname, rc)
          if (rc /= OH_XGB_SUCCESS) return
       end if
 
@@ -305,8 +396,8 @@ contains
       integer(c_int) :: crc
       logical :: ok
 
-      if (first_time) then
-         call one_time_setup(xgb_fname, rc)
+      if (first_time .or. model_policy /= OH_XGB_POLICY_REFERENCE) then
+         call select_booster(xgb_fname, rc)
          if (rc /= OH_XGB_SUCCESS) return
       end if
       call oh_xgb_k_slab(icount, jcount, kcount, dynamic_k_range, tropp_min, pl, tropp, k1, k2, rc)

@@ -58,12 +58,29 @@ def _fortran_flat(a: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(a.T, dtype=np.float32)
 
 
+def fill_grads_template(pattern: str, nymd: int, nhms: int = 0) -> str:
+    """The GrADS-style tokens MAPL's fill_grads_template expands in XGBoostFile
+    (OH_GridCompMod.F90:1187, OH_instance_OH.rc:20): %y4 %m2 %d2 %h2 %n2."""
+    return (pattern.replace("%y4", f"{nymd // 10000:04d}").replace("%m2", f"{nymd % 10000 // 100:02d}")
+            .replace("%d2", f"{nymd % 100:02d}").replace("%h2", f"{nhms // 10000:02d}")
+            .replace("%n2", f"{nhms % 10000 // 100:02d}"))
+
+
 class OHPredictor:
     """Holds the process-wide booster the reference keeps in SAVE variables
-    (``xx_bst``, ``first_time``; OH_GridCompMod.F90:182,209)."""
+    (``xx_bst``, ``first_time``; OH_GridCompMod.F90:182,209).
 
-    def __init__(self, lib=None):
+    ``model_policy``: "reference" keeps the booster of the FIRST call for good and ignores later
+    file names, as the reference does although XGBoostFile is month-templated (:209,269;
+    OH_instance_OH.rc:20); "by_name" keeps one resident booster per file name (twelve monthly
+    boosters are 0.56 GB of the 288 GB), so a month roll-over is a dictionary look-up."""
+
+    def __init__(self, lib=None, model_policy: str = "reference"):
+        if model_policy not in ("reference", "by_name"):
+            raise ValueError("model_policy must be 'reference' or 'by_name'")
         self.lib = lib
+        self.model_policy = model_policy
+        self.boosters: dict = {}
         self.xx_bst: Optional[capi.Booster] = None
         self.first_time = True
 
@@ -73,7 +90,10 @@ class OHPredictor:
         """Fills OH_ML[:, :, k1-1:k2] with 10**prediction (mol/mol); returns rc = 0.
 
         Raises AssertFailure where the reference's _ASSERT would fire."""
-        if self.first_time:                                            # ONE_TIME_SETUP, :242-271
+        name = xgb_fname.strip()
+        if self.model_policy == "by_name" and name in self.boosters:
+            self.xx_bst = self.boosters[name]
+        elif self.first_time or self.model_policy == "by_name":       # ONE_TIME_SETUP, :242-271
             xx_carr_small = np.zeros((1, XX_PARAM_COUNT), dtype=np.float32)
             try:
                 xx_dmtrx = capi.DMatrix(xx_carr_small, XX_MISS, lib=self.lib)          # :251
@@ -84,11 +104,12 @@ class OHPredictor:
             except capi.OhxError as e:
                 raise AssertFailure(f"Failed in XGBoosterCreate_f: {e}")
             try:
-                self.xx_bst.load_model(xgb_fname.strip())                              # :261
+                self.xx_bst.load_model(name)                                           # :261
             except capi.OhxError as e:
                 raise AssertFailure(f"Failed in XGBoosterLoadModel_f: {e}")
             xx_dmtrx.free()                                                            # :264
             self.first_time = False
+            self.boosters[name] = self.xx_bst
         assert pl.shape == (icount, jcount, kcount)
         k1, k2 = k_slab(pl, tropp, dynamic_k_range, tropp_min)
         ksubcount = k2 - k1 + 1

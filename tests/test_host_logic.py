@@ -135,3 +135,59 @@ def test_reference_binding_module_drives_the_oracle(tmp_path, small_model):
     pred = np.frombuffer(raw, dtype="<f4", count=n, offset=8)
     want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
     assert np.array_equal(helpers.bits(pred), helpers.bits(want))
+
+
+def _month_models(tmp_path, small_model):
+    other = synth.make_model(num_trees=20, max_depth=10, sample_log2=15, min_leaf=4, grid=synth.GRIDS["C12"],
+                             model_seed=77)
+    (tmp_path / "oh_M01.model").write_bytes(small_model.image.tobytes())
+    (tmp_path / "oh_M02.model").write_bytes(other.image.tobytes())
+    return tmp_path / "oh_M%m2.model", other
+
+
+@pytest.mark.parametrize("mode", ["compat", "fused"])
+def test_month_roll_over_policies_fortran_host(tmp_path, small_model, mode):
+    """XGBoostFile is month-templated (OH_instance_OH.rc:20) but the reference keeps the booster of its
+    first call for good (first_time, OH_GridCompMod.F90:209,269).  The Fortran host does the same by
+    default and, under OH_XGB_POLICY_BY_NAME, keeps one resident booster per file name instead."""
+    grid = synth.GRIDS["mock4x4"]
+    pl, tropp, fields = helpers.synth_state(grid)
+    state, out = tmp_path / "state.bin", tmp_path / "out.bin"
+    helpers.write_state_file(state, pl, tropp, fields, True, ohscale=1.0)
+    pattern, other = _month_models(tmp_path, small_model)
+    jan, _, _, _ = helpers.oracle_predict_oh(small_model.image, pl, tropp, fields, True)
+    feb, _, _, _ = helpers.oracle_predict_oh(other.image, pl, tropp, fields, True)
+    assert not np.array_equal(jan, feb)
+    for policy, want, resident in (("reference", jan, 0), ("by_name", feb, 2)):
+        r = helpers.run_driver(helpers.DRIVER_ORACLE, state, pattern, out, mode, 2, policy)   # calls dated Jan, Feb
+        assert r.returncode == 0, r.stdout
+        rc, _, _, oh, _ = helpers.read_driver_output(out, *grid)
+        tail = np.frombuffer(open(out, "rb").read()[-4:], dtype="<i4")[0]
+        assert rc == 0 and tail == resident
+        if mode == "compat":
+            assert np.array_equal(helpers.bits(oh), helpers.bits(want)), policy
+        else:
+            assert helpers.ulp_diff(oh, want).max() <= 2, policy
+
+
+def test_month_roll_over_policies_python_host(tmp_path, small_model, oracle_lib):
+    grid = synth.GRIDS["mock4x4"]
+    pl, tropp, fields = helpers.synth_state(grid)
+    pattern, other = _month_models(tmp_path, small_model)
+    assert oh_predict.fill_grads_template(str(pattern), 20240215, 123000).endswith("oh_M02.model")
+    assert oh_predict.fill_grads_template("a_%y4%m2%d2_%h2%n2.bin", 20231109, 63000) == "a_20231109_0630.bin"
+    jan, _, _, _ = helpers.oracle_predict_oh(small_model.image, pl, tropp, fields, True)
+    feb, _, _, _ = helpers.oracle_predict_oh(other.image, pl, tropp, fields, True)
+    for policy, want, resident in (("reference", jan, 1), ("by_name", feb, 2)):
+        p = oh_predict.OHPredictor(lib=oracle_lib, model_policy=policy)
+        oh = np.zeros(grid, dtype=np.float32)
+        for nymd in (20240115, 20240215):
+            oh[:] = 0
+            p.predict_OH_with_XGB(oh_predict.fill_grads_template(str(pattern), nymd), *grid, True, 4000.0, pl, tropp,
+                                  oh_predict.OHBoostInputData(fields), oh)
+        assert helpers.ulp_diff(oh, want).max() <= 2, policy          # numpy's 10**x against the oracle's powf
+        other_month = feb if want is jan else jan
+        assert helpers.ulp_diff(oh, other_month).max() > 1000
+        assert len(p.boosters) == resident
+    with pytest.raises(ValueError):
+        oh_predict.OHPredictor(model_policy="sometimes")
