@@ -326,3 +326,28 @@ def test_grid_hint_is_validated(torch_cuda):
             d.set_grid(*bad)
     d.set_grid(0, 0, 0)
     d.free()
+
+
+def test_month_roll_over_by_name_on_the_gpu(torch_cuda, tmp_path, small_model):
+    """Two monthly boosters resident in HBM, selected by the expanded file name (Fortran host, both routes)."""
+    grid = synth.GRIDS["C12"]
+    pl, tropp, fields = helpers.synth_state(grid)
+    state = tmp_path / "state.bin"
+    helpers.write_state_file(state, pl, tropp, fields, True, ohscale=1.0)
+    other = synth.make_model(num_trees=20, max_depth=10, sample_log2=15, min_leaf=4, grid=synth.GRIDS["C12"],
+                             model_seed=77)
+    (tmp_path / "oh_M01.model").write_bytes(small_model.image.tobytes())
+    (tmp_path / "oh_M02.model").write_bytes(other.image.tobytes())
+    (tmp_path / "oh_M03.model").write_bytes(small_model.image.tobytes())
+    for mode in ("compat", "fused"):
+        out_g, out_c = tmp_path / f"gpu_{mode}.bin", tmp_path / f"cpu_{mode}.bin"
+        for exe, out in ((helpers.DRIVER_HIP, out_g), (helpers.DRIVER_ORACLE, out_c)):
+            r = helpers.run_driver(exe, state, tmp_path / "oh_M%m2.model", out, mode, 3, "by_name")
+            assert r.returncode == 0, r.stdout
+            assert np.frombuffer(open(out, "rb").read()[-4:], dtype="<i4")[0] == 3
+        _, k1, _, oh_g, _ = helpers.read_driver_output(out_g, *grid)
+        _, _, _, oh_c, _ = helpers.read_driver_output(out_c, *grid)
+        if mode == "compat":
+            assert np.array_equal(helpers.bits(oh_g), helpers.bits(oh_c))
+        else:
+            assert helpers.ulp_diff(oh_g[:, :, k1 - 1:], oh_c[:, :, k1 - 1:]).max() <= 2
