@@ -289,7 +289,8 @@ def main():
     plane = grid[0] * grid[1]
     # pieces are whole levels when the shard is (bricks then have no idle lanes), else whole launches
     granule = plane if (use_grid and row0 % plane == 0 and n_local % plane == 0) else 64 * 256 * 20 * 2
-    pieces = shard.chunk_bounds(n_local, args.gather_chunks if (gather and even) else 1, granule)
+    round_rows = torch.cuda.get_device_properties(dev).multi_processor_count * 20 * 64   # one residency of the chip
+    pieces = shard.plan_pieces(n_local, args.gather_chunks if (gather and even) else 1, granule, round_rows)
     dmats = [capi.DMatrix(device_ptr=rows.data_ptr() + lo * synth.NFEAT * 4, nrow=hi - lo, ncol=synth.NFEAT,
                           missing=synth.XX_MISS) for lo, hi in pieces]
     if use_grid:

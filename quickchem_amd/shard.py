@@ -53,6 +53,31 @@ def chunk_bounds(n_local: int, nchunks: int, granule: int) -> list:
     return out
 
 
+def plan_pieces(n_local: int, max_pieces: int, granule: int, round_rows: int) -> list:
+    """Cut [0, n_local) into at most `max_pieces` pieces of whole granules (a grid level when the
+    waves take bricks) so that the pieces' all-gathers can overlap the next piece's prediction,
+    WITHOUT paying for it in idle waves: a piece occupies the GPU for ceil(rows / round_rows) rounds
+    (round_rows = rows one residency of the chip covers, 256 CUs x 20 waves x 64), so the plan with
+    the fewest rounds wins and, among equals, the one with the most pieces.  C360/8 = 9 levels:
+    three pieces of 3 levels take 24 rounds, two of 5 + 4 take 22, like the uncut shard."""
+    if max_pieces <= 1 or granule <= 0 or n_local <= granule:
+        return [(0, n_local)]
+    units = -(-n_local // granule)
+    best, best_rounds = [(0, n_local)], -(-n_local // round_rows)
+    for k in range(2, min(max_pieces, units) + 1):
+        base, rem = divmod(units, k)
+        sizes = [(base + (1 if q < rem else 0)) * granule for q in range(k)]
+        out, lo = [], 0
+        for sz in sizes:
+            hi = min(n_local, lo + sz)
+            out.append((lo, hi))
+            lo = hi
+        rounds = sum(-(-(hi - lo) // round_rows) for lo, hi in out)
+        if rounds <= best_rounds:
+            best, best_rounds = out, rounds
+    return best
+
+
 def all_gather_chunk_async(out_full: torch.Tensor, out_local: torch.Tensor, lo: int, hi: int, n_local: int, world: int):
     """Start gathering rows [lo, hi) of every rank's (equal-sized) shard straight into their
     final places in `out_full`; returns the work handle (wait() before reading out_full)."""

@@ -27,6 +27,22 @@ def test_row_shards_tile_the_batch():
     assert shard.row_shard(55_987_200, 8, 3) == (3 * 6_998_400, 6_998_400)
 
 
+def test_plan_pieces_never_costs_rounds():
+    plane, rr = 360 * 2160, 256 * 20 * 64
+    for levels, want in ((9, [5, 4]), (18, None), (36, None), (72, None), (1, [1])):
+        n = levels * plane
+        p = shard.plan_pieces(n, 4, plane, rr)
+        assert p[0][0] == 0 and p[-1][1] == n and all(a[1] == b[0] for a, b in zip(p, p[1:]))
+        assert all((hi - lo) % plane == 0 for lo, hi in p) and len(p) <= 4
+        assert sum(-(-(hi - lo) // rr) for lo, hi in p) <= -(-n // rr)        # no more rounds than uncut
+        if want:
+            assert [(hi - lo) // plane for lo, hi in p] == want
+    assert shard.plan_pieces(1000, 4, 0, rr) == [(0, 1000)] and shard.plan_pieces(10, 1, 2, 4) == [(0, 10)]
+    # ragged tail: the last piece is short
+    p = shard.plan_pieces(10 * plane + 17, 3, plane, rr)
+    assert p[-1][1] == 10 * plane + 17
+
+
 def test_chunk_bounds_cover_the_shard():
     for n_local in (1, 639, 640, 641, 6_998_400, 53_265_600):
         for k in (1, 2, 4, 7):
