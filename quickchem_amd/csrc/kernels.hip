@@ -244,6 +244,12 @@ __device__ __forceinline__ float walk_wide_tile(const uint4* __restrict__ nodes,
 // load: the wait would land there), keeps every gather a single global_load_dwordx4 and leaves
 // the other chains' gathers in flight behind a counted vmcnt.
 
+__device__ __forceinline__ bool go_left_or_default(float x, float thr, bool default_left) {
+  const bool lt = x < thr;
+  const bool not_ge = !(x >= thr);
+  return (bool)((int)(not_ge & default_left) | (int)(lt & !default_left));
+}
+
 // One step (two tree levels) of all chains.  There is no "finished" state: a lane that has taken its
 // leaf simply walks on, and emit_super guarantees that it lands on filler super-nodes (all codes 31,
 // all values +0.0, group 0 = four fillers) from then on, so OR-ing "the child's value if its code
@@ -268,7 +274,10 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
   for (int c = 0; c < CHAINS; ++c) {
     const uint32_t w = s[c].w;
     bool l = x0[c] < __uint_as_float(s[c].x);
-    if (HAS_MISSING) l = l || ((x0[c] != x0[c]) && ((w >> 5) & 1u));
+    // missing (NaN) -> default child.  "not >=" is "<" for numbers and true for NaN, so the default
+    // direction only picks which of two compares counts; bitwise on purpose (no short-circuit: hipcc
+    // turns || and && over lane predicates into divergent branches)
+    if (HAS_MISSING) l = go_left_or_default(x0[c], __uint_as_float(s[c].x), (w & 32u) != 0u);
     l0[c] = l;
     thr1[c] = l ? s[c].y : s[c].z;
     f1[c] = (w >> (l ? 0u : 13u)) & 31u;
@@ -280,7 +289,7 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
     leafb[c] |= (f1[c] == 31u) ? thr1[c] : 0u;
     if (!LAST) {
       bool l1 = x1[c] < __uint_as_float(thr1[c]);
-      if (HAS_MISSING) l1 = l1 || ((x1[c] != x1[c]) && ((w >> (l0[c] ? 6u : 7u)) & 1u));
+      if (HAS_MISSING) l1 = go_left_or_default(x1[c], __uint_as_float(thr1[c]), (w & (l0[c] ? 64u : 128u)) != 0u);
       rel[c] = ((w >> 18) << 2) + (l0[c] ? 0u : 2u) + (l1 ? 0u : 1u);
     }
   }
@@ -315,7 +324,7 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) {
       bool l = xr[c] < h[c].root_thr;
-      if (HAS_MISSING) l = l || ((xr[c] != xr[c]) && (h[c].root_meta & 32u));
+      if (HAS_MISSING) l = go_left_or_default(xr[c], h[c].root_thr, (h[c].root_meta & 32u) != 0u);
       tb[c] = reinterpret_cast<const char*>(nodes_v + h[c].base);
       // group 1 holds the root's super-node (phase 0) or those of its two children (phase 1)
       rel[c] = 4u + (((h[c].root_meta & 0x100u) && !l) ? 1u : 0u);
