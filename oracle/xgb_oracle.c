@@ -498,6 +498,20 @@ ORACLE_EXPORT int oracle_solar_geometry(int jday, const float* lats, const float
   return 0;
 }
 
+/* the same two under the product's names, so that the Fortran host of OH Run1 links against either library */
+ORACLE_EXPORT int OHXJulianDay(int nymd, int* jday) {
+  if (jday == NULL) return fail("OHXJulianDay: jday is NULL");
+  *jday = oracle_julian_day(nymd);
+  return 0;
+}
+ORACLE_EXPORT int OHXSolarGeometry(int jday, const float* lats, const float* lons, int im, int jm, float deg2rad,
+                                   float rad2deg, float* lat_deg, float* sza_noon) {
+  if (im < 0 || jm < 0) return fail("OHXSolarGeometry: im and jm must not be negative");
+  if ((size_t)im * (size_t)jm != 0 && (lats == NULL || (sza_noon != NULL && lons == NULL)))
+    return fail("OHXSolarGeometry: LATS (and LONS, for the zenith angle) must not be NULL");
+  return oracle_solar_geometry(jday, lats, lons, im, jm, deg2rad, rad2deg, lat_deg, sza_noon);
+}
+
 /* The product's layout hint (include/ohxgb.h); predictions do not depend on it, so the oracle
  * only checks the arguments. */
 ORACLE_EXPORT int OHXDMatrixSetGrid(void* dmat, int im, int jm, uint64_t row0) {

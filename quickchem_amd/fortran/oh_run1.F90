@@ -1,0 +1,170 @@
+!  oh_run1 -- Fortran host side of OHXBoosterRun1 (include/ohxgb.h part 3): the arithmetic of
+!  OH Run1 from the imports to the INTERNAL field OH in one device-resident pass
+!  (OH_GridComp/OH_GridCompMod.F90:1240-1257, 1444-1478, 1488, 1557-1595), plus the solar geometry
+!  of :401-466, 1444, 1481-1482.  Variable names are the reference's.  MAPL is not needed: its
+!  constants are arguments, and where the reference uses _ASSERT this module sets rc and an error
+!  text (oh_xgb_error_text of module oh_xgb_predict).
+module oh_run1
+   use, intrinsic :: iso_c_binding
+   use ohx_bindings, only: ohx_last_error
+   use oh_xgb_predict, only: oh_xgb_booster, OH_XGB_SUCCESS, OH_XGB_FAILURE
+   implicit none
+   private
+
+   public :: OH_RUN1_STATE, oh_run1_boost, oh_solar_geometry, oh_julian_day, oh_run1_error_text
+
+   !  struct OHXRun1Args, member for member
+   type, bind(C) :: OHXRun1Args
+      integer(c_int32_t) :: im, jm, km
+      integer(c_int32_t) :: dynamic_k_range
+      real(c_float)      :: tropp_min, ohscale, missing
+      real(c_float)      :: avogad, runiv, epsilon
+      type(c_ptr) :: ple_mod, t_mod, q_mod, tropp_mod
+      type(c_ptr) :: ple_bst, zle_bst, tauclw, taucli
+      type(c_ptr) :: scacoef(7)
+      type(c_ptr) :: gmito3, gmitto3
+      type(c_ptr) :: lat_deg, t_bst, no2, o3, ch4, co, isop, acet, c2h6, c3h8, prpe, alk4, mp, h2o2
+      type(c_ptr) :: cloud, qv, albuv, ch2o, sza
+      type(c_ptr) :: default_oh
+      type(c_ptr) :: oh, oh_boost, ndwet
+      type(c_ptr) :: k1, k2
+   end type
+
+   !  What Run1 has in hand when it reaches CALL_BOOST (:1557), by the reference's names.
+   !  Edge fields are (im,jm,0:km); scacoef are BC OC BR DU SU SS NI at the chosen wavelength (:1451-1458).
+   type OH_RUN1_STATE
+      real, pointer, dimension(:,:,:) :: PLE_MOD => null(), T_MOD => null(), Q_MOD => null()
+      real, pointer, dimension(:,:)   :: TROPP_MOD => null()
+      real, pointer, dimension(:,:,:) :: PLE_BST => null(), ZLE_BST => null(), TAUCLW => null(), TAUCLI => null()
+      real, pointer, dimension(:,:,:) :: BCscacoef => null(), OCscacoef => null(), BRscacoef => null(), &
+                                         DUscacoef => null(), SUscacoef => null(), SSscacoef => null(), &
+                                         NIscacoef => null()
+      real, pointer, dimension(:,:)   :: GMITO3 => null(), GMITTO3 => null(), latarr => null()
+      real, pointer, dimension(:,:,:) :: T_BST => null(), NO2 => null(), O3 => null(), CH4 => null(), CO => null(), &
+                                         ISOP => null(), ACET => null(), C2H6 => null(), C3H8 => null(), &
+                                         PRPE => null(), ALK4 => null(), MP => null(), H2O2 => null(), &
+                                         CLOUD => null(), QV => null(), CH2O => null()
+      real, pointer, dimension(:,:)   :: ALBUV => null(), sza_noon => null()
+      real, pointer, dimension(:,:,:) :: default_OH => null()
+   end type
+
+   interface
+      function OHXBoosterRun1(handle, args) bind(C, name="OHXBoosterRun1") result(rc)
+         import :: c_ptr, c_int, OHXRun1Args
+         type(c_ptr), value            :: handle
+         type(OHXRun1Args), intent(in) :: args
+         integer(c_int)                :: rc
+      end function
+      function OHXJulianDay(nymd, jday) bind(C, name="OHXJulianDay") result(rc)
+         import :: c_int
+         integer(c_int), value       :: nymd
+         integer(c_int), intent(out) :: jday
+         integer(c_int)              :: rc
+      end function
+      function OHXSolarGeometry(jday, lats, lons, im, jm, deg2rad, rad2deg, lat_deg, sza_noon) &
+            bind(C, name="OHXSolarGeometry") result(rc)
+         import :: c_int, c_float
+         integer(c_int), value      :: jday, im, jm
+         real(c_float), intent(in)  :: lats(*), lons(*)
+         real(c_float), value       :: deg2rad, rad2deg
+         real(c_float), intent(out) :: lat_deg(*), sza_noon(*)
+         integer(c_int)             :: rc
+      end function
+   end interface
+
+   character(len=512), save :: last_error = ''
+
+contains
+
+   function oh_run1_error_text() result(msg)
+      character(len=:), allocatable :: msg
+      msg = trim(last_error)
+   end function
+
+   integer function oh_julian_day(nymd)                       ! JulianDay (:1905-1936)
+      integer, intent(in) :: nymd
+      integer(c_int) :: jd, crc
+      crc = OHXJulianDay(int(nymd, c_int), jd)
+      oh_julian_day = jd
+   end function
+
+   !  latarr = LATS*MAPL_RADIANS_TO_DEGREES (:1444); sza_noon = computeSolarZenithAngle_LocalNoon (:1482)
+   subroutine oh_solar_geometry(jday, LATS, LONS, degrees_to_radians, radians_to_degrees, latarr, sza_noon, rc)
+      integer, intent(in) :: jday
+      real, intent(in), contiguous  :: LATS(:,:), LONS(:,:)
+      real, intent(in)  :: degrees_to_radians, radians_to_degrees
+      real, intent(out), contiguous :: latarr(:,:), sza_noon(:,:)
+      integer, intent(out) :: rc
+      integer(c_int) :: crc
+      rc = OH_XGB_SUCCESS
+      crc = OHXSolarGeometry(int(jday, c_int), LATS, LONS, int(size(LATS,1), c_int), int(size(LATS,2), c_int), &
+                             degrees_to_radians, radians_to_degrees, latarr, sza_noon)
+      if (crc /= 0) then
+         last_error = 'Failed in OHXSolarGeometry :: '//ohx_last_error()
+         rc = OH_XGB_FAILURE
+      end if
+   end subroutine
+
+   type(c_ptr) function loc3(a)
+      real, pointer, intent(in) :: a(:,:,:)
+      loc3 = c_null_ptr
+      if (associated(a)) loc3 = c_loc(a(lbound(a,1), lbound(a,2), lbound(a,3)))
+   end function
+
+   type(c_ptr) function loc2(a)
+      real, pointer, intent(in) :: a(:,:)
+      loc2 = c_null_ptr
+      if (associated(a)) loc2 = c_loc(a(lbound(a,1), lbound(a,2)))
+   end function
+
+   !  CALL_BOOST and what surrounds it (:1444-1478, 1488, 1557-1595) in one call.
+   !  OH is the INTERNAL field (molec/cm3), OH_boost the export OH_ML*OHscale, NDWET the diagnostic.
+   subroutine oh_run1_boost(XGBoostFilename, im, jm, km, dynamic_k_range, tropp_min, OHscale, &
+                            avogad, runiv, epsilon, st, OH, OH_boost, NDWET, k1, k2, rc)
+      character(len=*), intent(in) :: XGBoostFilename
+      integer, intent(in)  :: im, jm, km
+      logical, intent(in)  :: dynamic_k_range
+      real, intent(in)     :: tropp_min, OHscale, avogad, runiv, epsilon
+      type(OH_RUN1_STATE), intent(in) :: st
+      real, intent(out), target, contiguous :: OH(:,:,:), OH_boost(:,:,:), NDWET(:,:,:)
+      integer, intent(out) :: k1, k2, rc
+      type(OHXRun1Args) :: a
+      type(c_ptr) :: bst
+      integer(c_int32_t), target :: ck1, ck2
+      integer(c_int) :: crc
+
+      k1 = 0
+      k2 = 0
+      call oh_xgb_booster(XGBoostFilename, bst, rc)
+      if (rc /= OH_XGB_SUCCESS) then
+         last_error = 'oh_run1_boost: the booster could not be loaded'
+         return
+      end if
+      a%im = im; a%jm = jm; a%km = km
+      a%dynamic_k_range = merge(1, 0, dynamic_k_range)
+      a%tropp_min = tropp_min; a%ohscale = OHscale; a%missing = -999.0     ! :213
+      a%avogad = avogad; a%runiv = runiv; a%epsilon = epsilon
+      a%ple_mod = loc3(st%PLE_MOD); a%t_mod = loc3(st%T_MOD); a%q_mod = loc3(st%Q_MOD); a%tropp_mod = loc2(st%TROPP_MOD)
+      a%ple_bst = loc3(st%PLE_BST); a%zle_bst = loc3(st%ZLE_BST); a%tauclw = loc3(st%TAUCLW); a%taucli = loc3(st%TAUCLI)
+      a%scacoef(1) = loc3(st%BCscacoef); a%scacoef(2) = loc3(st%OCscacoef); a%scacoef(3) = loc3(st%BRscacoef)
+      a%scacoef(4) = loc3(st%DUscacoef); a%scacoef(5) = loc3(st%SUscacoef); a%scacoef(6) = loc3(st%SSscacoef)
+      a%scacoef(7) = loc3(st%NIscacoef)
+      a%gmito3 = loc2(st%GMITO3); a%gmitto3 = loc2(st%GMITTO3); a%lat_deg = loc2(st%latarr)
+      a%t_bst = loc3(st%T_BST); a%no2 = loc3(st%NO2); a%o3 = loc3(st%O3); a%ch4 = loc3(st%CH4); a%co = loc3(st%CO)
+      a%isop = loc3(st%ISOP); a%acet = loc3(st%ACET); a%c2h6 = loc3(st%C2H6); a%c3h8 = loc3(st%C3H8)
+      a%prpe = loc3(st%PRPE); a%alk4 = loc3(st%ALK4); a%mp = loc3(st%MP); a%h2o2 = loc3(st%H2O2)
+      a%cloud = loc3(st%CLOUD); a%qv = loc3(st%QV); a%albuv = loc2(st%ALBUV); a%ch2o = loc3(st%CH2O)
+      a%sza = loc2(st%sza_noon); a%default_oh = loc3(st%default_OH)
+      a%oh = c_loc(OH(1,1,1)); a%oh_boost = c_loc(OH_boost(1,1,1)); a%ndwet = c_loc(NDWET(1,1,1))
+      a%k1 = c_loc(ck1); a%k2 = c_loc(ck2)
+      crc = OHXBoosterRun1(bst, a)
+      if (crc /= 0) then
+         last_error = 'Failed in OHXBoosterRun1 :: '//ohx_last_error()
+         rc = OH_XGB_FAILURE
+         return
+      end if
+      k1 = ck1
+      k2 = ck2
+   end subroutine
+
+end module oh_run1

@@ -20,7 +20,7 @@ module oh_xgb_predict
 
    public :: OH_BOOST_INPUT_DATA, predict_OH_with_XGB, predict_OH_with_XGB_fused
    public :: oh_xgb_k_slab, oh_xgb_reset, oh_xgb_error_text
-   public :: oh_xgb_set_model_policy, oh_xgb_fill_template, oh_xgb_resident_models
+   public :: oh_xgb_set_model_policy, oh_xgb_fill_template, oh_xgb_resident_models, oh_xgb_booster
 
    !  Which booster a call uses when the file name changes between calls.  The reference keeps the
    !  booster of the FIRST call for the life of the process and ignores later names, although the
@@ -199,6 +199,16 @@ contains
       if (crc /= 0) then; call fail('Failed in XGDMatrixFree_f', rc); return; end if
       deallocate(xx_carr_small)
       first_time = .false.
+   end subroutine
+
+   !  The booster a call on this file name uses, loaded if need be (for callers of the OHX* entry points)
+   subroutine oh_xgb_booster(xgb_fname, bst, rc)
+      character(len=*), intent(in) :: xgb_fname
+      type(c_ptr), intent(out) :: bst
+      integer, intent(out) :: rc
+      rc = OH_XGB_SUCCESS
+      if (first_time .or. model_policy /= OH_XGB_POLICY_REFERENCE) call select_booster(xgb_fname, rc)
+      bst = xx_bst
    end subroutine
 
    !  The slab of levels that needs a prediction (:275-301)

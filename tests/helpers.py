@@ -163,3 +163,31 @@ def run1_state(grid, seed=17):
                      ("ch2o", 1e-12)):
         st[name] = (f32(lo) * np.exp2(u(0, 8, vol))).astype(f32)
     return st
+
+
+RUN1_DRIVER_HIP = os.path.join(ROOT, "quickchem_amd", "lib", "oh_run1_driver_hip")
+RUN1_DRIVER_ORACLE = os.path.join(ROOT, "oracle", "lib", "oh_run1_driver_oracle")
+# the order quickchem_amd/fortran/oh_run1_driver.F90 reads the state in
+RUN1_FILE_ORDER = ["ple_mod", "t_mod", "q_mod", "tropp_mod", "ple_bst", "zle_bst", "tauclw", "taucli", "scacoef",
+                   "gmito3", "gmitto3", "lat_deg", "t_bst", "no2", "o3", "ch4", "co", "isop", "acet", "c2h6", "c3h8",
+                   "prpe", "alk4", "mp", "h2o2", "cloud", "qv", "albuv", "ch2o", "sza", "default_oh"]
+
+
+def write_run1_state_file(path, st, dynamic_k_range, tropp_min=4000.0, ohscale=0.85, avogad=6.023e26, runiv=8314.47,
+                          epsilon=18.015 / 28.965):
+    im, jm, km = st["t_mod"].shape
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iiiifffff", im, jm, km, 1 if dynamic_k_range else 0, tropp_min, ohscale, avogad, runiv,
+                            epsilon))
+        for name in RUN1_FILE_ORDER:
+            for a in (st[name] if name == "scacoef" else [st[name]]):
+                f.write(fortran_flat(a).tobytes())
+
+
+def read_run1_output(path, im, jm, km):
+    raw = open(path, "rb").read()
+    rc, k1, k2 = struct.unpack_from("<iii", raw, 0)
+    n = im * jm * km
+    out = [np.ascontiguousarray(np.frombuffer(raw, dtype="<f4", count=n, offset=12 + 4 * n * q)
+                                .reshape(km, jm, im).transpose(2, 1, 0)) for q in range(3)]
+    return rc, k1, k2, out[0], out[1], out[2]

@@ -158,3 +158,45 @@ def test_solar_geometry_gpu_against_the_oracle():
     lib = capi.load_library()
     with pytest.raises(capi.OhxError, match="LATS"):
         capi.check(lib, lib.OHXSolarGeometry(80, None, None, 4, 4, 0.0, 0.0, None, None))
+
+
+def test_run1_fortran_host_on_the_oracle(tmp_path, small_model):
+    """quickchem_amd/fortran/oh_run1.F90 (bind(C) mirror of OHXRun1Args, the reference's variable names)
+    driving OHXBoosterRun1: same library underneath, so the Fortran host must reproduce the Python
+    host's result to the bit."""
+    grid = (9, 7, 24)
+    st = helpers.run1_state(grid, seed=3)
+    state, model, out = tmp_path / "run1.bin", tmp_path / "oh.model", tmp_path / "out.bin"
+    helpers.write_run1_state_file(state, st, True)
+    model.write_bytes(small_model.image.tobytes())
+    r = helpers.run_driver(helpers.RUN1_DRIVER_ORACLE, state, model, out)
+    assert r.returncode == 0, r.stdout
+    rc, k1, k2, oh, boost, ndwet = helpers.read_run1_output(out, *grid)
+    ref = oracle_run1(small_model.image, st, dynamic_k_range=True)
+    assert rc == 0 and (k1, k2) == (ref["k1"], ref["k2"])
+    for got, name in ((oh, "oh"), (boost, "oh_boost"), (ndwet, "ndwet")):
+        assert np.array_equal(helpers.bits(got), helpers.bits(ref[name])), name
+
+
+@pytest.mark.gpu
+def test_run1_fortran_host_on_the_gpu(tmp_path, small_model):
+    grid = (40, 25, 72)
+    st = helpers.run1_state(grid, seed=9)
+    state, model = tmp_path / "run1.bin", tmp_path / "oh.model"
+    helpers.write_run1_state_file(state, st, True)
+    model.write_bytes(small_model.image.tobytes())
+    outs = {}
+    for tag, exe in (("gpu", helpers.RUN1_DRIVER_HIP), ("cpu", helpers.RUN1_DRIVER_ORACLE)):
+        out = tmp_path / f"{tag}.bin"
+        r = helpers.run_driver(exe, state, model, out)
+        assert r.returncode == 0, r.stdout
+        outs[tag] = helpers.read_run1_output(out, *grid)
+    (rc, k1, k2, oh, boost, ndwet), (rc2, k1c, k2c, oh_c, boost_c, ndwet_c) = outs["gpu"], outs["cpu"]
+    assert rc == 0 and rc2 == 0 and (k1, k2) == (k1c, k2c)
+    assert np.array_equal(helpers.bits(ndwet), helpers.bits(ndwet_c))
+    assert helpers.ulp_diff(boost[:, :, k1 - 1:], boost_c[:, :, k1 - 1:]).max() <= 2
+    assert helpers.ulp_diff(oh, oh_c).max() <= 3
+    # and the Python host on the same library: identical
+    b = capi.Booster(model_buffer=small_model.image)
+    py = b.run1(st, dynamic_k_range=True)
+    assert np.array_equal(helpers.bits(oh), helpers.bits(py["oh"])) and (k1, k2) == (py["k1"], py["k2"])
