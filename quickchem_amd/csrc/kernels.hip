@@ -34,7 +34,7 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Node arrays are read through a buffer descriptor: one 64-/128-bit load per node that the
+// The packed 8-byte nodes are read through a buffer descriptor: one 64-bit load per node that the
 // compiler cannot split into dword loads (it does split a plain uint2 load when only one half
 // is needed early, which doubles the gathers), a 32-bit offset instead of a 64-bit address,
 // and a hardware range check.
@@ -45,11 +45,6 @@ __device__ __forceinline__ uint2 load_node8(__amdgpu_buffer_rsrc_t r, uint32_t s
   const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(slot << 3), 0, 0);
   return make_uint2(v.x, v.y);
 }
-__device__ __forceinline__ uint4 load_node16(__amdgpu_buffer_rsrc_t r, uint32_t slot) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(slot << 4), 0, 0);
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
-
 __device__ __forceinline__ bool is_inf(float v) { return __builtin_isinf(v); }
 
 // ------------------------------------------------------------------ lanes -> rows
@@ -163,15 +158,6 @@ __device__ __forceinline__ bool store_row27(float* __restrict__ tile, const Row2
 }
 
 // ------------------------------------------------------------------ walks
-
-template <bool HAS_MISSING>
-__device__ __forceinline__ uint32_t step_packed(uint2 nd, const float* __restrict__ tile) {
-  const float x = tile[(nd.y & 31u) * kWave];
-  const float cond = __uint_as_float(nd.x);
-  bool go_left = x < cond;
-  if (HAS_MISSING) go_left = go_left || ((x != x) && (nd.y & 32u));
-  return (nd.y >> 6) - (go_left ? 1u : 0u);
-}
 
 // Packed walk, CHAINS trees at once per lane.  The loop body is straight-line code: all
 // feature reads (LDS), one wait, all compares, all node gathers - so the chains' LDS and
