@@ -281,9 +281,17 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
   }
 }
 
+// `first`: the block's LDS copy of every tree's first-step super-nodes (kFirstTrees trees, two
+// entries each: the root's children, or the root's own super-node twice), filled by the kernel.
+// The first gather of a walk is the cheapest for the L1 (one block per tree) but costs the
+// texture addresser its fixed ~11 cycles like any other; from LDS it costs it nothing.
+constexpr uint32_t kFirstTrees = 128;
+constexpr uint32_t kFirstBytes = kFirstTrees * 2 * 16;
+
 template <int CHAINS, bool HAS_MISSING>
 __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const SuperTreeHead* __restrict__ heads,
-                                            uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile) {
+                                            uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile,
+                                            const char* __restrict__ first, uint32_t nfirst) {
   if (t0 >= t1) return acc;
   const u32x4* __restrict__ nodes_v = reinterpret_cast<const u32x4*>(nodes);
   const char* tile_b = reinterpret_cast<const char*>(tile);
@@ -321,8 +329,16 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
     uint32_t nsteps = h[0].steps;
 #pragma unroll
     for (int c = 1; c < CHAINS; ++c) nsteps = h[c].steps > nsteps ? h[c].steps : nsteps;
+    if (t + CHAINS <= nfirst) {
 #pragma unroll
-    for (int c = 0; c < CHAINS; ++c) s[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)(rel[c] << 4));
+      for (int c = 0; c < CHAINS; ++c) {
+        const uint32_t tt = (t + c < t1) ? t + c : t1 - 1;
+        s[c] = *reinterpret_cast<const u32x4*>(first + ((2u * tt + (rel[c] - 4u)) << 4));
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) s[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)(rel[c] << 4));
+    }
     for (uint32_t step = 1; step < nsteps; ++step) {
       super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
 #pragma unroll
@@ -339,7 +355,8 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 // FMT: 0 = wide 16-byte nodes, 1 = packed 8-byte nodes, 2 = 16-byte super-nodes
 template <int FMT, int CHAINS>
 __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads, uint32_t t0,
-                                           uint32_t t1, const float* tile, bool wave_has_missing) {
+                                           uint32_t t1, const float* tile, bool wave_has_missing, const char* first,
+                                           uint32_t nfirst) {
   float acc = fr.base_score;
   if constexpr (FMT == 1) {
     const __amdgpu_buffer_rsrc_t nodes = make_rsrc(fr.packed, fr.packed_bytes);
@@ -348,13 +365,29 @@ __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTr
   } else if constexpr (FMT == 2) {
     // plain 128-bit global loads: measured 8 % faster than buffer loads on the divergent deep levels
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.super);
-    return wave_has_missing ? walk_super<CHAINS, true>(nodes, heads, t0, t1, acc, tile)
-                            : walk_super<CHAINS, false>(nodes, heads, t0, t1, acc, tile);
+    return wave_has_missing ? walk_super<CHAINS, true>(nodes, heads, t0, t1, acc, tile, first, nfirst)
+                            : walk_super<CHAINS, false>(nodes, heads, t0, t1, acc, tile, first, nfirst);
   } else {
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
     return wave_has_missing ? walk_wide_tile<true>(nodes, fr.roots, t0, t1, acc, tile)
                             : walk_wide_tile<false>(nodes, fr.roots, t0, t1, acc, tile);
   }
+}
+
+// Fills the block's first-step table (walk_super) - one entry per thread - and returns how many
+// trees it covers.  Every thread of the block must call it (it ends in a barrier).
+template <int FMT>
+__device__ __forceinline__ uint32_t fill_first_steps(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads,
+                                                     char* first) {
+  if constexpr (FMT != 2) return 0u;
+  const uint32_t nfirst = fr.num_trees < kFirstTrees ? fr.num_trees : kFirstTrees;
+  for (uint32_t e = threadIdx.x; e < 2u * nfirst; e += blockDim.x) {
+    const SuperTreeHead h = heads[e >> 1];
+    const uint32_t slot = h.base + 4u + ((h.root_meta & 0x100u) ? (e & 1u) : 0u);
+    reinterpret_cast<u32x4*>(first)[e] = reinterpret_cast<const u32x4*>(fr.super)[slot];
+  }
+  __syncthreads();
+  return nfirst;
 }
 
 // ------------------------------------------------------------------ kernels
@@ -370,7 +403,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  float* tile = lds + (size_t)wave * fr.num_feature * kWave + lane;
+  char* first = reinterpret_cast<char*>(lds);
+  float* tile = lds + (FMT == 2 ? kFirstBytes / 4 : 0) + (size_t)wave * fr.num_feature * kWave + lane;
+  const uint32_t nfirst = fill_first_steps<FMT>(fr, heads, first);
   const bool missing_is_nan = a.missing != a.missing;
   // Blocks b and b + 8 share an XCD (round-robin dispatch, observed, speed only): give
   // every XCD one contiguous run of tiles so that its CUs walk neighbouring gridcells and
@@ -398,7 +433,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
         load_row27(regs, a.rows, valid ? row : 0);   // in flight during the walk
       }
       const bool wave_nan = __any(lane_nan);
-      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan);
+      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
       if (this_valid) __builtin_nontemporal_store(acc, out + this_row);
       tile_id = next;
     }
@@ -411,7 +446,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
                                          missing_is_nan, a.flags);
     const bool wave_nan = __any(lane_nan);
     // the tile is private to this wave: its own LDS writes are ordered before its reads
-    const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan);
+    const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
     if (valid) __builtin_nontemporal_store(acc, out + row);
   }
 }
@@ -461,7 +496,9 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  float* tile = lds + (size_t)wave * fr.num_feature * kWave + lane;
+  char* first = reinterpret_cast<char*>(lds);
+  float* tile = lds + (FMT == 2 ? kFirstBytes / 4 : 0) + (size_t)wave * fr.num_feature * kWave + lane;
+  const uint32_t nfirst = fill_first_steps<FMT>(fr, heads, first);
   const bool missing_is_nan = a.missing != a.missing;
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
   const uint64_t nrow = plane * (uint64_t)(a.k2 - a.k1 + 1);
@@ -490,7 +527,7 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
     }
     if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
     const bool wave_nan = __any(lane_nan);
-    const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan);
+    const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
     if (valid) {
       if (margin_out) margin_out[m] = acc;
       float oh = acc;
@@ -700,8 +737,8 @@ int grid_for(uint64_t work_items, int num_cus, int blocks_per_cu) {
 // ignores the value; for the last wave of a block that address lies past the allocation, where
 // an LDS read returns zero (the hardware range-checks LDS addresses; no fault).  Padding the
 // allocation instead costs a whole block of occupancy per CU (5 x 28 928 B no longer fits).
-size_t tile_lds_bytes(uint32_t num_feature) {
-  return (size_t)kWavesPerBlock * num_feature * kWave * sizeof(float);
+size_t tile_lds_bytes(uint32_t num_feature, bool super_format) {
+  return (size_t)kWavesPerBlock * num_feature * kWave * sizeof(float) + (super_format ? kFirstBytes : 0);
 }
 
 template <class K>
@@ -782,10 +819,10 @@ const char* kernel_kind_name(KernelKind k) {
 hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const PredictArgs& a, int num_cus,
                           hipStream_t stream, const LaunchTuning& tune) {
   if (a.nrow == 0) return hipSuccess;
-  const size_t lds = tile_lds_bytes(fr.num_feature);
-  const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && a.ncol <= fr.num_feature;
   const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
                         kind == KernelKind::Super4 || kind == KernelKind::Super5 || kind == KernelKind::Super6;
+  const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
+  const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && a.ncol <= fr.num_feature;
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
   if (a.pred_leaf || kind == KernelKind::Wide || !tile_ok || (!is_super && fr.packed == nullptr)) {
     if (fr.wide == nullptr) return hipErrorInvalidValue;
@@ -845,10 +882,10 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
                                  hipStream_t stream, const LaunchTuning& tune) {
   if (a.k2 < a.k1 || a.im <= 0 || a.jm <= 0) return hipSuccess;
   const uint64_t nrow = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)(a.k2 - a.k1 + 1);
-  const size_t lds = tile_lds_bytes(fr.num_feature);
-  if (fr.num_feature < 1 || lds > 160 * 1024) return hipErrorInvalidValue;
   const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
                         kind == KernelKind::Super4 || kind == KernelKind::Super5 || kind == KernelKind::Super6;
+  const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
+  if (fr.num_feature < 1 || lds > 160 * 1024) return hipErrorInvalidValue;
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
   const bool use_wide = kind == KernelKind::Wide || (!is_super && fr.packed == nullptr);
   if (use_wide && fr.wide == nullptr) return hipErrorInvalidValue;
