@@ -75,6 +75,14 @@ constexpr uint64_t kPackedMaxSlots = 1ull << 26;
 //              18-31 group index, relative to the tree's base, of the four grandchild
 //                    super-nodes [LL, LR, RL, RR] stored contiguously (64 B)
 // next = tree_base + 4 * group + 2 * go_right(node) + go_right(child)
+//
+// Fillers.  Group 0 of every tree is four filler super-nodes - all three codes 31, all three
+// values +0.0, group 0 - and so is every slot of a group that lies below a leaf.  A lane that has
+// taken its leaf therefore keeps stepping through fillers (and ends up on group 0, shared by all
+// finished lanes of the tree): the kernel needs no per-lane "finished" state, it ORs "the child's
+// value if its code is 31" into the lane's leaf bits - the real leaf once, zero bits afterwards.
+// Group 1 is where a walk starts: the root's super-node at slot 4 (phase 0) or the super-nodes of
+// the root's two children at slots 4 and 5 (phase 1).
 struct SuperNode {
   float thr0, thrL, thrR;
   uint32_t meta;
@@ -86,7 +94,7 @@ constexpr uint32_t super_meta(uint32_t f0, uint32_t fl, uint32_t fr, uint32_t dl
 }
 constexpr uint32_t kSuperMaxGroups = 1u << 14;
 
-// Per tree: where the walk starts.  Phase-0 trees start at super-node `base`.  Phase-1 trees
+// Per tree: where the walk starts.  Phase-0 trees start at super-node base + 4.  Phase-1 trees
 // (super-nodes start at odd levels) evaluate the root from this record - it is the same for
 // every lane, so it comes through scalar loads - and start at base + 4 + go_right(root).
 struct SuperTreeHead {
