@@ -177,6 +177,19 @@ def measured_traffic(grid_name, kernel, model_nodes):
     return best
 
 
+def gather_issue(info, nrows, kernel_s, dev):
+    import torch
+    props = torch.cuda.get_device_properties(dev)
+    tiles = -(-nrows // 64)
+    gathers = tiles * (info.get("gathers_per_wave", 0) + 7)          # + the 7 loads of a tile's 27-float rows
+    clock_hz = 2.4e9                                                 # MI355X max clock (MI355X_MICROARCH.md)
+    peak = props.multi_processor_count * clock_hz / 14.0
+    return {"unit": "wave64 gathers/s", "achieved": gathers / kernel_s, "peak": peak,
+            "frac": gathers / kernel_s / peak,
+            "gathers_per_wave_and_tree": info.get("gathers_per_wave", 0) / max(info["num_trees"], 1),
+            "min_cycles_per_gather": 14, "cus": props.multi_processor_count, "clock_mhz": clock_hz / 1e6}
+
+
 def bench_fields(args, grid, n_total, model, booster, dev, t_model):
     """The fused SoA variant (23 3-D reads + 4 2-D reads + 1 write per gridcell)."""
     from quickchem_amd import synth
@@ -387,7 +400,10 @@ def main():
                          "per": "step = the train of launches of one pass over the batch",
                          "launches_per_step": launches_per_step,
                          "avg_launch_us": kernel_s * 1e6 / launches_per_step,
-                         "algorithmic_bytes": algo_bytes},
+                         "algorithmic_bytes": algo_bytes,
+                         # what actually bounds the walk: gather instructions through the
+                         # texture addresser, priced at the 14 cycles a wave64 gather costs at the very least
+                         "gather_issue": gather_issue(info, n_local, kernel_s, dev)},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

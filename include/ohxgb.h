@@ -213,7 +213,8 @@ int OHXSolarGeometryDevice(int jday, const float* d_lats, const float* d_lons, i
 
 /* Model facts for roofline accounting: info[0] trees, [1] nodes in the model,
  * [2] node slots in HBM, [3] bytes of the node array the selected kernel reads,
- * [4] max depth, [5] features, [6] 1 if the packed 8-byte format is in use. */
+ * [4] max depth, [5] features, [6] node format in use (0 wide, 1 packed, 2 super-nodes),
+ * [7] gather instructions one wavefront issues to walk the whole forest once (super-nodes). */
 int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]);
 
 /* Synthetic inputs of SURVEY.md §8(d), generated in HBM (device pointers):

@@ -313,7 +313,8 @@ class Booster:
     def info(self) -> dict:
         arr = (C.c_uint64 * 8)()
         check(self.lib, self.lib.OHXBoosterGetInfo(self.handle, arr))
-        keys = ["num_trees", "num_nodes", "num_slots", "node_bytes", "max_depth", "num_feature", "packed"]
+        keys = ["num_trees", "num_nodes", "num_slots", "node_bytes", "max_depth", "num_feature", "packed",
+                "gathers_per_wave"]
         return {k: int(arr[i]) for i, k in enumerate(keys)}
 
     def free(self) -> None:

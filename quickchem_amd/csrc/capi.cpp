@@ -163,6 +163,7 @@ struct BoosterObj {
   DevBuf<SuperTreeHead> d_super_heads;
   bool super_ok = false;
   uint64_t super_slots = 0;
+  uint64_t super_gathers = 0;   // gathers a wave issues to walk the whole forest once (steps not served from LDS)
   DevBuf<uint32_t> d_roots;
   DevBuf<uint32_t> d_flags;
   DevBuf<float> d_pred;
@@ -205,6 +206,13 @@ KernelKind pick_kernel(const BoosterObj& b) {
   return KernelKind::Packed2;
 }
 
+// Steps of every tree, less the first step of the trees whose start nodes sit in the kernels' LDS table
+uint64_t count_super_gathers(const SuperForest& sf) {
+  uint64_t n = 0;
+  for (size_t t = 0; t < sf.heads.size(); ++t) n += sf.heads[t].steps - (t < kFirstStepTrees && sf.heads[t].steps ? 1u : 0u);
+  return n;
+}
+
 bool wants_super(const std::string& k) { return k == "auto" || (k.size() == 6 && k.compare(0, 5, "super") == 0); }
 
 void invalidate_device_state(BoosterObj& b) {
@@ -238,6 +246,7 @@ void ensure_uploaded(BoosterObj& b) {
     b.super_ok = emit_super(b.forest, &sf) && sf.nodes.size() * sizeof(SuperNode) < 0xFFFFFFF0ull;
     if (b.super_ok) {
       b.super_slots = sf.nodes.size();
+      b.super_gathers = count_super_gathers(sf);
       b.d_super.upload(sf.nodes);
       b.d_super_heads.upload(sf.heads);
     }
@@ -1003,7 +1012,7 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
   }
   const bool packed_used = packed_ok && b->kernel_name != "wide";
   bool super_used = false;
-  uint64_t super_slots = b->super_slots;
+  uint64_t super_slots = b->super_slots, super_gathers = b->super_gathers;
   if (wants_super(b->kernel_name)) {
     if (b->uploaded) {
       super_used = b->super_ok;
@@ -1011,6 +1020,7 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
       SuperForest sf;
       super_used = emit_super(b->forest, &sf);
       super_slots = sf.nodes.size();
+      super_gathers = count_super_gathers(sf);
     }
   }
   info[0] = b->forest.trees.size();
@@ -1021,7 +1031,7 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
   info[4] = (bst_ulong)p->max_depth;
   info[5] = b->forest.num_feature;
   info[6] = super_used ? 2 : (packed_used ? 1 : 0);
-  info[7] = 0;
+  info[7] = super_used ? super_gathers : 0;
   API_END();
 }
 

@@ -285,7 +285,7 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
 // entries each: the root's children, or the root's own super-node twice), filled by the kernel.
 // The first gather of a walk is the cheapest for the L1 (one block per tree) but costs the
 // texture addresser its fixed ~11 cycles like any other; from LDS it costs it nothing.
-constexpr uint32_t kFirstTrees = 128;
+constexpr uint32_t kFirstTrees = kFirstStepTrees;
 constexpr uint32_t kFirstBytes = kFirstTrees * 2 * 16;
 
 template <int CHAINS, bool HAS_MISSING>

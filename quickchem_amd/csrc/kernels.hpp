@@ -13,6 +13,9 @@ enum : uint32_t {
   kFlagInfInput = 1u,  // an input value was +-inf while `missing` is finite
 };
 
+// trees whose first-step super-nodes the tile kernels keep in LDS (kernels.hip)
+constexpr uint32_t kFirstStepTrees = 128;
+
 struct DeviceForest {
   const PackedNode* packed = nullptr;   // may be null (booster does not qualify)
   const WideNode* wide = nullptr;       // may be null until first needed
