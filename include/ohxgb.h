@@ -123,6 +123,13 @@ int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong nc
  * neighbours in all three directions walk the same tree nodes.  im = jm = 0 withdraws the hint. */
 int OHXDMatrixSetGrid(DMatrixHandle handle, int im, int jm, bst_ulong row0);
 
+/* What the library knows about the rows of a DMatrix (any pointer may be NULL).  Without a hint,
+ * XGDMatrixCreateFromMat looks for the level size by itself: the reference's gather stacks levels and
+ * its first column, LAT, is a 2-D field (OH_GridCompMod.F90:313), so that column repeats bit for bit
+ * with period im*jm.  A period found that way is reported as im = level size, jm = 1, inferred = 1 and
+ * is worth as much as the full hint to within 1 % (runs of 8 cells x 8 levels per wavefront). */
+int OHXDMatrixGetGrid(DMatrixHandle handle, int* im, int* jm, bst_ulong* row0, int* inferred);
+
 /* Predict straight into device memory: d_out[nrow] margins (or [nrow][ntree]
  * leaf ids with option_mask 16).  `stream` is a hipStream_t (NULL = default
  * stream); the call only enqueues work.  OHXBoosterCheck surfaces errors the

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "XGBGetLastError", "XGDMatrixCreateFromMat", "XGDMatrixFree", "XGDMatrixNumRow", "XGDMatrixNumCol",
     "XGDMatrixSaveBinary", "XGDMatrixCreateFromFile", "XGBoosterCreate", "XGBoosterFree", "XGBoosterLoadModel",
     "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
-    "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
+    "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device",
     "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXSynthRowsDevice",
     "OHXSynthFieldDevice", "OHXInjectMissingDevice",
@@ -95,6 +95,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.OHXDeviceCount.argtypes = [C.POINTER(i32)]
     lib.OHXDMatrixCreateFromDevice.argtypes = [vp, u64, u64, f32, C.POINTER(vp)]
     lib.OHXDMatrixSetGrid.argtypes = [vp, i32, i32, u64]
+    lib.OHXDMatrixGetGrid.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64), C.POINTER(i32)]
     lib.OHXBoosterPredictDevice.argtypes = [vp, vp, i32, C.c_uint, vp, vp]
     lib.OHXBoosterCheck.argtypes = [vp, vp]
     lib.OHXBoosterPredictFields.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), i32, i32, i32, i32, i32, i32, i32,
@@ -181,6 +182,12 @@ class DMatrix:
         """OHXDMatrixSetGrid: the rows are rows row0.. of the (im, jm, *) gather (speed only)."""
         check(self.lib, self.lib.OHXDMatrixSetGrid(self.handle, im, jm, row0))
         return self
+
+    def grid(self):
+        """OHXDMatrixGetGrid -> (im, jm, row0, inferred)."""
+        im, jm, r0, inf = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_int32()
+        check(self.lib, self.lib.OHXDMatrixGetGrid(self.handle, C.byref(im), C.byref(jm), C.byref(r0), C.byref(inf)))
+        return im.value, jm.value, r0.value, bool(inf.value)
 
     def save_binary(self, fname: str) -> None:
         check(self.lib, self.lib.XGDMatrixSaveBinary(self.handle, fname.encode(), 1))

@@ -548,6 +548,28 @@ __global__ __launch_bounds__(kBlock) void scan_dense_kernel(const float* __restr
   if (any_inf && !is_inf(missing)) atomicOr(flags, kFlagInfInput);
 }
 
+// Is column `col` of the row-major matrix periodic in the rows with period cand[b]?  One block per
+// candidate period, 4 x blockDim sampled row pairs each, bit-for-bit.  This is how a matrix gathered
+// level by level from a grid shows its level size without being told: a 2-D field (LAT, feature 0 of
+// the OH gather, OH_GridCompMod.F90:313) repeats exactly from one level to the next.
+__global__ __launch_bounds__(kBlock) void detect_period_kernel(const float* __restrict__ data, uint64_t nrow,
+                                                               uint32_t ncol, uint32_t col,
+                                                               const uint64_t* __restrict__ cand,
+                                                               uint32_t* __restrict__ mismatch) {
+  const uint64_t period = cand[blockIdx.x];
+  const uint64_t span = nrow - period;
+  const uint32_t* bits = reinterpret_cast<const uint32_t*>(data);
+  bool bad = false;
+  for (uint32_t s = threadIdx.x; s < 4u * blockDim.x; s += blockDim.x) {
+    const uint64_t m = ((uint64_t)ohx_hash4(0x5eedu, s, blockIdx.x, 0u, 0u) * 2654435761ull + s) % span;
+    bad |= bits[m * ncol + col] != bits[(m + period) * ncol + col];
+  }
+  // the first and the last pair as well
+  if (threadIdx.x == 0) bad |= bits[col] != bits[period * ncol + col] ||
+                               bits[(span - 1) * ncol + col] != bits[(nrow - 1) * ncol + col];
+  if (bad) atomicOr(&mismatch[blockIdx.x], 1u);
+}
+
 // ------------------------------------------------------------------ OH Run1: before and after the predict
 
 // Feature engineering in two kernels.  (1) pointwise, one thread per gridcell: PL_BST, the
@@ -946,6 +968,14 @@ hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, u
   if (count == 0) return hipSuccess;
   hipLaunchKernelGGL(scan_dense_kernel, dim3(grid_for(count / 4 + 1, 256, 8)), dim3(kBlock), 0, stream, data, count,
                      missing, flags);
+  return hipGetLastError();
+}
+
+hipError_t launch_detect_period(const float* data, uint64_t nrow, uint32_t ncol, uint32_t col, const uint64_t* d_cand,
+                                uint32_t ncand, uint32_t* d_mismatch, hipStream_t stream) {
+  if (ncand == 0) return hipSuccess;
+  hipLaunchKernelGGL(detect_period_kernel, dim3(ncand), dim3(kBlock), 0, stream, data, nrow, ncol, col, d_cand,
+                     d_mismatch);
   return hipGetLastError();
 }
 

@@ -61,8 +61,13 @@ struct TileShape {
   // The brick that wastes the fewest lanes, preferring the more compact one on a tie within a few
   // percent (measured on the C360 step: 4x4x4 36.4 ms, 8x4x2 36.6 ms, 8x8x1 37.1 ms).
   void set_grid_auto(uint32_t im_, uint32_t jm_, uint64_t row0_, uint64_t nrow_) {
-    static const uint32_t cand[3][3] = {{2, 2, 2}, {3, 2, 1}, {3, 3, 0}};
-    static const double speed[3] = {1.0, 0.994, 0.98};
+    // jm == 1: only the level size is known (im = cells per level): runs of cells x levels, measured on the
+    // C360 step at 34.8 / 35.2 / 37.0 ms for 8x1x8 / 16x1x4 / 32x1x2 (4x4x4 with the full grid: 34.6 ms)
+    static const uint32_t cand3[3][3] = {{2, 2, 2}, {3, 2, 1}, {3, 3, 0}};
+    static const uint32_t cand1[3][3] = {{3, 0, 3}, {4, 0, 2}, {5, 0, 1}};
+    static const double speed3[3] = {1.0, 0.994, 0.98}, speed1[3] = {1.0, 0.99, 0.94};
+    const uint32_t (*cand)[3] = jm_ == 1 ? cand1 : cand3;
+    const double* speed = jm_ == 1 ? speed1 : speed3;
     double best = -1.0;
     int pick = 0;
     for (int q = 0; q < 3; ++q) {
@@ -174,6 +179,9 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& forest, const Pre
 hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& forest, const FieldsArgs& a, int num_cus,
                                  hipStream_t stream, const LaunchTuning& tune = LaunchTuning());
 hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream);
+// d_mismatch[c] != 0 afterwards <=> column `col` is NOT periodic with period d_cand[c] (sampled); all device pointers
+hipError_t launch_detect_period(const float* data, uint64_t nrow, uint32_t ncol, uint32_t col, const uint64_t* d_cand,
+                                uint32_t ncand, uint32_t* d_mismatch, hipStream_t stream);
 
 // synthetic inputs (synth_common.h), generated in HBM
 hipError_t launch_synth_rows(uint32_t seed, int im, int jm, int km, uint64_t row_begin, uint64_t nrows, float* out,

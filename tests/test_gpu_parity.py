@@ -351,3 +351,31 @@ def test_month_roll_over_by_name_on_the_gpu(torch_cuda, tmp_path, small_model):
             assert np.array_equal(helpers.bits(oh_g), helpers.bits(oh_c))
         else:
             assert helpers.ulp_diff(oh_g[:, :, k1 - 1:], oh_c[:, :, k1 - 1:]).max() <= 2
+
+
+def test_level_size_is_inferred_from_the_rows(torch_cuda, small_model):
+    """No hint: XGDMatrixCreateFromMat finds the level size of a level-stacked gather from the exact
+    repetition of its first column (LAT) and tiles by it; predictions are the same bit for bit.  An explicit
+    hint overrides it; rows that are not level-stacked (shuffled, a ragged shard) are left alone."""
+    # a 96 x 72 grid (a level of 6 912 cells, above the library's minimum of 4 096), 12 levels
+    wide = synth.rows_cpu((96, 72, 72), 0, 96 * 72 * 12)
+    want = helpers.oracle_predict(small_model.image, wide, synth.XX_MISS)
+    d = capi.DMatrix(wide, missing=synth.XX_MISS)
+    assert d.grid() == (96 * 72, 1, 0, True)
+    b = capi.Booster(model_buffer=small_model.image)
+    assert np.array_equal(helpers.bits(b.predict(d)), helpers.bits(want))
+    d.set_grid(96, 72, 0)
+    assert d.grid() == (96, 72, 0, False)
+    assert np.array_equal(helpers.bits(b.predict(d)), helpers.bits(want))
+    d.free()
+    # a ragged shard (not whole levels) and shuffled rows: nothing to find, nothing breaks
+    for arr in (wide[1000:-500], wide[np.random.default_rng(3).permutation(len(wide))]):
+        d = capi.DMatrix(arr, missing=synth.XX_MISS)
+        assert d.grid()[3] is False and d.grid()[0] == 0
+        got = b.predict(d)
+        assert np.array_equal(helpers.bits(got), helpers.bits(helpers.oracle_predict(small_model.image, arr, synth.XX_MISS)))
+        d.free()
+    # too small to bother (fewer than 2 x 4096 rows)
+    d = capi.DMatrix(wide[:5000], missing=synth.XX_MISS)
+    assert d.grid() == (0, 0, 0, False)
+    d.free()
