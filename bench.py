@@ -85,9 +85,18 @@ def cpu_baseline(model_image, rows_dev, budget_s):
     n = int(min(rows_dev.shape[0], max(probe, 0.7 * rate * budget_s)))
     n = max(64, n // 64 * 64)
     t, out = run(n)
+    # how one GEOS rank runs it (one thread), on a slice sized to about two seconds
+    lib.oracle_set_num_threads.argtypes = [C.c_int]
+    lib.oracle_set_num_threads(1)
+    tp, _ = run(8192)
+    n1 = max(8192, int(min(n, 2.0 * 8192 / max(tp, 1e-6))) // 64 * 64)
+    t1, _ = run(n1)
+    lib.oracle_set_num_threads(cores)
     return {"value": n / t, "unit": "gridcells/s", "cores": cores, "kind": "port",
             "sample": f"first {n} rows of the batch, oracle/xgb_oracle.c (OpenMP, {cores} threads), "
-                      f"XGDMatrixCreateFromMat + XGBoosterPredict, {t:.2f} s"}, out, n
+                      f"XGDMatrixCreateFromMat + XGBoosterPredict, {t:.2f} s",
+            "one_thread": {"value": n1 / t1, "unit": "gridcells/s", "cores": 1,
+                           "sample": f"first {n1} rows, {t1:.2f} s"}}, out, n
 
 
 def bench_run1(args, grid, n_total, model, booster, dev, t_model):
