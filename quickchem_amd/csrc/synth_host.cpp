@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "flatten.hpp"
 #include "forest.hpp"
 #include "synth_common.h"
 
@@ -251,6 +252,70 @@ int ohx_model_convert(const uint8_t* in_buf, uint64_t in_len, int format, uint8_
       *out_buf = (uint8_t*)malloc(b.size());
       memcpy(*out_buf, b.data(), b.size());
       *out_len = b.size();
+    }
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// Host check of the super-node layout (flatten.hpp), for the CPU test-suite: walks emit_super's arrays
+// the way the kernels do - the root from the head record (phase 1), a fixed `steps` iterations per tree,
+// no finished state, the leaf OR-ed in whenever the child's code is 31, fillers after it - so that a
+// layout bug shows without a GPU.  Not a prediction path: scalar, test support only.
+// out[nrow] margins; info[0] = super-nodes, info[1] = trees that start below the root (phase 1),
+// info[2] = total steps.  Returns 1 if the booster does not fit the format.
+int ohx_super_walk_cpu(const uint8_t* model, uint64_t model_len, const float* rows, uint64_t nrow, uint32_t ncol,
+                       float missing, float* out, uint64_t* info) {
+  try {
+    Forest f = load_model_buffer(model, (size_t)model_len);
+    f.validate();
+    SuperForest sf;
+    if (!emit_super(f, &sf)) return 1;
+    uint64_t phase1 = 0, steps = 0;
+    for (const SuperTreeHead& h : sf.heads) {
+      phase1 += (h.root_meta >> 8) & 1u;
+      steps += h.steps;
+    }
+    if (info) {
+      info[0] = sf.nodes.size();
+      info[1] = phase1;
+      info[2] = steps;
+    }
+    const bool missing_is_nan = missing != missing;
+    std::vector<float> x(32, 0.0f);   // rows 27..31 "belong to nobody"
+    for (uint64_t r = 0; r < nrow; ++r) {
+      for (uint32_t c = 0; c < 32; ++c) {
+        float v = c < ncol ? rows[r * ncol + c] : (c < f.num_feature ? NAN : 0.0f);
+        if (c < ncol && !missing_is_nan && v == missing) v = NAN;
+        x[c] = v;
+      }
+      float acc = f.base_score;
+      for (const SuperTreeHead& h : sf.heads) {
+        auto left = [](float xv, float thr, bool dl) { return xv != xv ? dl : xv < thr; };
+        uint32_t rel = 4u;
+        if (h.root_meta & 0x100u) rel += left(x[h.root_meta & 31u], h.root_thr, (h.root_meta & 32u) != 0) ? 0u : 1u;
+        uint32_t leaf_bits = 0;
+        for (uint32_t step = 0; step < h.steps; ++step) {
+          const SuperNode& s = sf.nodes[h.base + rel];
+          const uint32_t w = s.meta;
+          const bool l0 = left(x[(w >> 8) & 31u], s.thr0, ((w >> 5) & 1u) != 0);
+          const float thr1 = l0 ? s.thrL : s.thrR;
+          const uint32_t f1 = (w >> (l0 ? 0u : 13u)) & 31u;
+          if (f1 == 31u) {
+            uint32_t b;
+            memcpy(&b, &thr1, 4);
+            leaf_bits |= b;
+          }
+          const bool l1 = left(x[f1], thr1, ((w >> (l0 ? 6u : 7u)) & 1u) != 0);
+          rel = ((w >> 18) << 2) + (l0 ? 0u : 2u) + (l1 ? 0u : 1u);
+        }
+        float leaf;
+        memcpy(&leaf, &leaf_bits, 4);
+        acc += leaf;
+      }
+      out[r] = acc;
     }
     return 0;
   } catch (const std::exception& e) {

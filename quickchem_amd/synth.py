@@ -59,6 +59,8 @@ def _load():
         lib.ohx_synth_set_threads.argtypes = [C.c_int]
         lib.ohx_model_convert.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_uint64)]
+        lib.ohx_super_walk_cpu.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_float,
+                                           C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = lib
     return _lib
 
@@ -133,6 +135,23 @@ def convert_model(image, fmt: str) -> np.ndarray:
     code = {"binary": 0, "json": 1, "ubj": 2}[fmt]
     _check(lib.ohx_model_convert(src.ctypes.data, src.nbytes, code, C.byref(out), C.byref(n)))
     return _take(out, n.value)
+
+
+def super_walk_cpu(image, rows: np.ndarray, missing: float = XX_MISS):
+    """Host check of the super-node layout the kernels read (csrc/flatten.hpp): emit_super's arrays walked
+    the kernels' way - fixed trip count per tree, no finished state, fillers - by a scalar loop.  Test
+    support, not a prediction path.  Returns (margins, info) or (None, None) if the booster does not fit."""
+    lib = _load()
+    src = np.frombuffer(bytes(image), dtype=np.uint8) if not isinstance(image, np.ndarray) else image
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    out = np.empty(rows.shape[0], dtype=np.float32)
+    info = (C.c_uint64 * 4)()
+    rc = lib.ohx_super_walk_cpu(src.ctypes.data, src.nbytes, rows.ctypes.data, rows.shape[0], rows.shape[1], missing,
+                                out.ctypes.data, info)
+    if rc == 1:
+        return None, None
+    _check(rc)
+    return out, {"super_nodes": int(info[0]), "phase1_trees": int(info[1]), "steps": int(info[2])}
 
 
 # ---- device generators (torch tensors in HBM; libohxgb.so) ----

@@ -93,6 +93,39 @@ def test_oracles_agree_on_random_boosters(ntree, nfeat, depth, p_leaf):
                           helpers.oracle_predict(binary, rows, -999.0, option_mask=16).reshape(len(rows), -1))
 
 
+@pytest.mark.parametrize("ntree,nfeat,depth,p_leaf", CASES)
+def test_super_node_layout_walks_like_the_oracle(ntree, nfeat, depth, p_leaf):
+    """The layout the default kernel reads (16-byte super-nodes, fillers instead of a finished state, a fixed
+    trip count per tree, start nodes in group 1), walked on the host the kernel's way: same margins as the
+    oracle, bit for bit, for every shape of tree - or an honest "does not fit" (more than 31 features)."""
+    rng = np.random.default_rng(ntree * 1000 + nfeat)
+    js = random_booster_json(rng, ntree, nfeat, depth, p_leaf)
+    rows = random_rows(rng, 3000, nfeat)
+    model = O.load_model(js)
+    for missing in (-999.0, float("nan")):
+        got, info = synth.super_walk_cpu(js, rows, missing)
+        if nfeat > 31:
+            assert got is None
+            continue
+        assert np.array_equal(helpers.bits(got), helpers.bits(O.predict(model, rows, missing=missing))), missing
+        assert info["steps"] >= ntree and info["super_nodes"] >= 8 * ntree
+    if nfeat <= 31 and nfeat > 2:
+        # fewer columns than features: the absent ones are missing
+        got, _ = synth.super_walk_cpu(js, rows[:, :nfeat - 2], -999.0)
+        assert np.array_equal(helpers.bits(got), helpers.bits(O.predict(model, rows[:, :nfeat - 2], missing=-999.0)))
+
+
+def test_super_node_layout_on_the_oh_boosters(small_model, deep_model):
+    for m in (small_model, deep_model):
+        rows = synth.rows_cpu(synth.GRIDS["C12"], 100, 4000)
+        rows[::17, 3] = np.nan
+        rows[5::29, 1] = synth.XX_MISS
+        got, info = synth.super_walk_cpu(m.image, rows)
+        assert np.array_equal(helpers.bits(got), helpers.bits(helpers.oracle_predict(m.image, rows, synth.XX_MISS)))
+        # depth-capped trees start below the root (phase 1): depth 10 -> 5 steps, depth 18 -> 9
+        assert info["phase1_trees"] == m.num_trees and info["steps"] == m.num_trees * (m.max_depth // 2)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ntree,nfeat,depth,p_leaf", CASES)
 def test_gpu_kernels_on_random_boosters(ntree, nfeat, depth, p_leaf):
