@@ -91,7 +91,7 @@ void Forest::validate() const {
       if (t.left[(size_t)i] == -1) continue;
       // xgboost 1.6.0's predictor steps to LeftChild() + !(fvalue < cond): it
       // takes right == left + 1 for granted; a file that breaks it is refused.
-      if (t.right[(size_t)i] != t.left[(size_t)i] + 1)
+      if ((int64_t)t.right[(size_t)i] != (int64_t)t.left[(size_t)i] + 1)
         throw OhxError("tree " + std::to_string(ti) + ": right child is not left child + 1");
       if (num_feature != 0 && t.feature[(size_t)i] >= num_feature)
         throw OhxError("tree " + std::to_string(ti) + ": split feature " + std::to_string(t.feature[(size_t)i]) +
@@ -434,7 +434,23 @@ struct UbjReader {
   }
   static bool is_number(uint8_t t) { return strchr("iUIlLdD", (int)t) != nullptr && t != 0; }
 
+  int depth = 0;
+  // a count read from the file: there cannot be more elements than there are bytes left (payload-free
+  // types - T, F, Z - included: no writer emits millions of those)
+  int64_t container_count() {
+    ++off;
+    const int64_t count = integer(byte());
+    if (count < 0 || (uint64_t)count > len - off + 64) fail("implausible element count");
+    return count;
+  }
+
   json::Value value(uint8_t t) {
+    struct Depth {
+      int& d;
+      explicit Depth(int& dd) : d(dd) { ++d; }
+      ~Depth() { --d; }
+    } guard(depth);
+    if (depth > 64) fail("nested too deeply");
     json::Value v;
     if (t == 'Z') return v;
     if (t == 'T' || t == 'F') { v.type = json::Value::Bool; v.b = (t == 'T'); return v; }
@@ -446,7 +462,7 @@ struct UbjReader {
       uint8_t elem = 0;
       int64_t count = -1;
       if (peek() == '$') { ++off; elem = byte(); if (peek() != '#') fail("'$' without '#'"); }
-      if (peek() == '#') { ++off; count = integer(byte()); if (count < 0) fail("negative count"); }
+      if (peek() == '#') count = container_count();
       if (elem != 0 && (is_number(elem) || elem == 'T' || elem == 'F')) {
         v.type = json::Value::NumArray;
         v.nums.reserve((size_t)count);
@@ -481,7 +497,7 @@ struct UbjReader {
       uint8_t elem = 0;
       int64_t count = -1;
       if (peek() == '$') { ++off; elem = byte(); if (peek() != '#') fail("'$' without '#'"); }
-      if (peek() == '#') { ++off; count = integer(byte()); if (count < 0) fail("negative count"); }
+      if (peek() == '#') count = container_count();
       for (int64_t i = 0; count < 0 || i < count; ++i) {
         uint8_t kt = byte();
         if (count < 0 && kt == '}') break;

@@ -138,7 +138,17 @@ class Parser {
     return out;
   }
 
+  // a model document nests six deep; a file that nests without end is refused, not recursed into
+  struct Depth {
+    int& d;
+    explicit Depth(int& dd) : d(dd) { ++d; }
+    ~Depth() { --d; }
+  };
+  int depth_ = 0;
+
   Value value() {
+    Depth guard(depth_);
+    if (depth_ > 64) fail("nested too deeply");
     ws();
     if (p_ >= end_) fail("unexpected end of input");
     Value v;

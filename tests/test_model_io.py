@@ -162,3 +162,29 @@ def test_ubjson_round_trip_and_predictions(small_model, tmp_path):
     assert np.array_equal(O.predict(m, np.float32([[0.5], [1.0], [np.nan]])), np.float32([0.0, 2.5, 0.0]))
     got = helpers.oracle_predict(synth.convert_model(doc, "binary"), np.float32([[0.5], [1.0], [np.nan]]), float("nan"))
     assert np.array_equal(got, np.float32([0.0, 2.5, 0.0]))
+
+
+def test_model_readers_survive_mutated_files_under_sanitizers(tmp_path, small_model):
+    """tools/fuzz_models.cpp, built with AddressSanitizer + UBSan (CPU only): thousands of truncated, bit-flipped,
+    spliced legacy-binary / JSON / UBJSON images go through the readers and the flatteners; each is either
+    accepted or refused with an error - no crash, no out-of-bounds access, no runaway allocation."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "quickchem_amd", "csrc")
+    exe = tmp_path / "fuzz_models"
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+                            "-fno-sanitize-recover=undefined", "-fopenmp", "-I", src,
+                            os.path.join(root, "tools", "fuzz_models.cpp"), os.path.join(src, "forest_io.cpp"),
+                            os.path.join(src, "flatten.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert build.returncode == 0, build.stderr[-2000:]
+    seed_model = synth.make_model(num_trees=6, max_depth=6, sample_log2=12, min_leaf=2, grid=synth.GRIDS["C12"])
+    model = tmp_path / "seed.model"
+    model.write_bytes(seed_model.image.tobytes())
+    for seed in (11, 12):
+        r = subprocess.run([str(exe), str(model), "4000", str(seed)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "0 crashes" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
