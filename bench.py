@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--missing-ppm", type=int, default=0, help="inject -999.0/NaN at this rate per million entries")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--shuffle", action="store_true", help="permute the rows (destroys spatial coherence)")
+    ap.add_argument("--infer-grid", action="store_true",
+                    help="rows path: no hint either, but let the library look for the level size in the rows "
+                         "(OHXDMatrixInferGrid), as XGDMatrixCreateFromMat does unasked for host matrices")
     ap.add_argument("--no-grid", action="store_true",
                     help="rows path: do not tell the library which grid the rows come from (OHXDMatrixSetGrid); "
                          "waves then take 64 consecutive rows instead of bricks of neighbouring gridcells")
@@ -307,7 +310,7 @@ def main():
     even = (n_total % world == 0)
     # pieces of the shard: one DMatrix view each (device pointers into `rows`)
     gather = world > 1 or force_dist
-    use_grid = not (args.no_grid or args.shuffle)
+    use_grid = not (args.no_grid or args.shuffle or args.infer_grid)
     plane = grid[0] * grid[1]
     # pieces are whole levels when the shard is (bricks then have no idle lanes), else whole launches
     granule = plane if (use_grid and row0 % plane == 0 and n_local % plane == 0) else 64 * 256 * 20 * 2
@@ -318,6 +321,9 @@ def main():
     if use_grid:
         for (lo, hi), dm in zip(pieces, dmats):
             dm.set_grid(grid[0], grid[1], row0 + lo)
+    elif args.infer_grid:
+        for dm in dmats:
+            dm.infer_grid()
     out_full = torch.empty(n_total, dtype=torch.float32, device=dev) if gather else out_local
     stream = torch.cuda.current_stream()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -398,7 +404,7 @@ def main():
                           "node_slots": info["num_slots"], "node_bytes": info["node_bytes"],
                           "mean_path": round(model.mean_path, 3), "seed": synth.MODEL_SEED,
                           "build_s": round(t_model, 2)},
-                "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid),
+                "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid), "grid_inferred": bool(args.infer_grid),
                 "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -130,6 +130,11 @@ int OHXDMatrixSetGrid(DMatrixHandle handle, int im, int jm, bst_ulong row0);
  * is worth as much as the full hint to within 1 % (runs of 8 cells x 8 levels per wavefront). */
 int OHXDMatrixGetGrid(DMatrixHandle handle, int* im, int* jm, bst_ulong* row0, int* inferred);
 
+/* The same search on demand, for a DMatrix over device memory (OHXDMatrixCreateFromDevice cannot look:
+ * the rows need not be there yet).  Waits for `stream`, then looks; *found (may be NULL) says whether a
+ * level size was found.  Replaces any earlier hint. */
+int OHXDMatrixInferGrid(DMatrixHandle handle, void* stream, int* found);
+
 /* Predict straight into device memory: d_out[nrow] margins (or [nrow][ntree]
  * leaf ids with option_mask 16).  `stream` is a hipStream_t (NULL = default
  * stream); the call only enqueues work.  OHXBoosterCheck surfaces errors the

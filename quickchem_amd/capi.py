@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "XGBGetLastError", "XGDMatrixCreateFromMat", "XGDMatrixFree", "XGDMatrixNumRow", "XGDMatrixNumCol",
     "XGDMatrixSaveBinary", "XGDMatrixCreateFromFile", "XGBoosterCreate", "XGBoosterFree", "XGBoosterLoadModel",
     "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
-    "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
+    "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXDMatrixInferGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device",
     "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXSynthRowsDevice",
     "OHXSynthFieldDevice", "OHXInjectMissingDevice",
@@ -96,6 +96,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.OHXDMatrixCreateFromDevice.argtypes = [vp, u64, u64, f32, C.POINTER(vp)]
     lib.OHXDMatrixSetGrid.argtypes = [vp, i32, i32, u64]
     lib.OHXDMatrixGetGrid.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u64), C.POINTER(i32)]
+    lib.OHXDMatrixInferGrid.argtypes = [vp, vp, C.POINTER(i32)]
     lib.OHXBoosterPredictDevice.argtypes = [vp, vp, i32, C.c_uint, vp, vp]
     lib.OHXBoosterCheck.argtypes = [vp, vp]
     lib.OHXBoosterPredictFields.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), i32, i32, i32, i32, i32, i32, i32,
@@ -182,6 +183,12 @@ class DMatrix:
         """OHXDMatrixSetGrid: the rows are rows row0.. of the (im, jm, *) gather (speed only)."""
         check(self.lib, self.lib.OHXDMatrixSetGrid(self.handle, im, jm, row0))
         return self
+
+    def infer_grid(self, stream: int = 0) -> bool:
+        """OHXDMatrixInferGrid: look for the level size in the rows (device matrices; waits for `stream`)."""
+        found = C.c_int32()
+        check(self.lib, self.lib.OHXDMatrixInferGrid(self.handle, stream or None, C.byref(found)))
+        return bool(found.value)
 
     def grid(self):
         """OHXDMatrixGetGrid -> (im, jm, row0, inferred)."""

@@ -436,6 +436,18 @@ int OHXDMatrixGetGrid(DMatrixHandle handle, int* im, int* jm, bst_ulong* row0, i
   API_END();
 }
 
+int OHXDMatrixInferGrid(DMatrixHandle handle, void* stream, int* found) {
+  API_BEGIN();
+  DMatrixObj* d = as_dmat(handle);
+  HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // the rows must be there
+  d->grid_im = d->grid_jm = 0;
+  d->grid_row0 = 0;
+  d->grid_inferred = false;
+  infer_level_size(*d);
+  if (found) *found = d->grid_inferred ? 1 : 0;
+  API_END();
+}
+
 int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong ncol, float missing, DMatrixHandle* out) {
   API_BEGIN();
   if (out == nullptr) throw OhxError("OHXDMatrixCreateFromDevice: out is NULL");
