@@ -375,6 +375,17 @@ def test_level_size_is_inferred_from_the_rows(torch_cuda, small_model):
         got = b.predict(d)
         assert np.array_equal(helpers.bits(got), helpers.bits(helpers.oracle_predict(small_model.image, arr, synth.XX_MISS)))
         d.free()
+    # a matrix over device memory: nothing is looked at on creation, OHXDMatrixInferGrid looks on demand
+    t = torch_cuda.from_numpy(wide).cuda()
+    dd = capi.DMatrix(device_ptr=t.data_ptr(), nrow=wide.shape[0], ncol=27, missing=synth.XX_MISS)
+    assert dd.grid() == (0, 0, 0, False)
+    assert dd.infer_grid() is True and dd.grid() == (96 * 72, 1, 0, True)
+    out = torch_cuda.empty(wide.shape[0], dtype=torch_cuda.float32, device="cuda")
+    b.predict_device(dd, out.data_ptr())
+    torch_cuda.cuda.synchronize()
+    b.check()
+    assert np.array_equal(helpers.bits(out.cpu().numpy()), helpers.bits(want))
+    dd.free()
     # too small to bother (fewer than 2 x 4096 rows)
     d = capi.DMatrix(wide[:5000], missing=synth.XX_MISS)
     assert d.grid() == (0, 0, 0, False)
