@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--infer-grid", action="store_true",
                     help="rows path: no hint either, but let the library look for the level size in the rows "
                          "(OHXDMatrixInferGrid), as XGDMatrixCreateFromMat does unasked for host matrices")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed steps rank 0 predicts the whole batch in one piece, untiled, and compares "
+                         "the gathered field with it bit for bit (small grids: it generates all rows on rank 0)")
     ap.add_argument("--no-grid", action="store_true",
                     help="rows path: do not tell the library which grid the rows come from (OHXDMatrixSetGrid); "
                          "waves then take 64 consecutive rows instead of bricks of neighbouring gridcells")
@@ -257,8 +260,12 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal of the multi-rank path on a one-GPU box: OHX_BENCH_SHARE_GPU=1 puts every rank on device 0
+    # (RCCL refuses two ranks on one device, so OHX_BENCH_BACKEND=gloo goes with it); never for numbers
+    dev_index = 0 if os.environ.get("OHX_BENCH_SHARE_GPU") == "1" else local_rank
+    backend = os.environ.get("OHX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     force_dist = os.environ.get("OHX_BENCH_FORCE_DIST") == "1"     # exercise the RCCL calls with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist
@@ -267,7 +274,10 @@ def main():
         if force_dist and world == 1:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     from quickchem_amd import capi, shard, synth
 
@@ -363,6 +373,28 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    verified = None
+    if args.verify:
+        ok = 1
+        if rank == 0:
+            all_rows = torch.empty((n_total, synth.NFEAT), dtype=torch.float32, device=dev)
+            synth.rows_device(grid, 0, n_total, all_rows)
+            if args.missing_ppm:
+                raise SystemExit("--verify regenerates the rows: not with --missing-ppm")
+            ref = torch.empty(n_total, dtype=torch.float32, device=dev)
+            dm_all = capi.DMatrix(device_ptr=all_rows.data_ptr(), nrow=n_total, ncol=synth.NFEAT, missing=synth.XX_MISS)
+            booster.predict_device(dm_all, ref.data_ptr(), stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            booster.check()
+            ok = int(torch.equal(ref.view(torch.int32), out_full.view(torch.int32)))
+            del all_rows, ref
+        if world > 1:
+            t = torch.tensor([ok], dtype=torch.int64, device=dev)
+            dist.broadcast(t, src=0)
+            ok = int(t.item())
+        verified = bool(ok)
+        if not verified:
+            raise SystemExit("bench --verify: the gathered field differs from the one-piece prediction")
     kernel_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
     kernel_s = float(np.mean(kernel_ms)) * 1e-3
     if world > 1:
@@ -404,7 +436,7 @@ def main():
                           "node_slots": info["num_slots"], "node_bytes": info["node_bytes"],
                           "mean_path": round(model.mean_path, 3), "seed": synth.MODEL_SEED,
                           "build_s": round(t_model, 2)},
-                "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid), "grid_inferred": bool(args.infer_grid),
+                "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid), "grid_inferred": bool(args.infer_grid), "verified": verified,
                 "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

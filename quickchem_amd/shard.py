@@ -21,17 +21,26 @@ def row_shard(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return row0, n
 
 
+def _gather_flat(out: torch.Tensor, inp: torch.Tensor, world: int) -> None:
+    """all_gather_into_tensor, or its list form under gloo on GPU tensors (rehearsals on a shared GPU)."""
+    if dist.get_backend() == "gloo" and inp.is_cuda:
+        n = inp.numel()
+        dist.all_gather([out[r * n:(r + 1) * n] for r in range(world)], inp)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
 def all_gather_rows(out_full: torch.Tensor, out_local: torch.Tensor, n_total: int, world: int, even: bool) -> None:
     """Every rank ends with the whole field, shards in rank (= row) order."""
     if even:
-        dist.all_gather_into_tensor(out_full, out_local)
+        _gather_flat(out_full, out_local, world)
         return
     # ragged shards: gather fixed-size slots, then compact
     slot = (n_total + world - 1) // world
     padded = out_local.new_zeros(slot)
     padded[: out_local.numel()] = out_local
     slots = out_local.new_empty(world * slot)
-    dist.all_gather_into_tensor(slots, padded)
+    _gather_flat(slots, padded, world)
     for r in range(world):
         row0, n = row_shard(n_total, world, r)
         out_full[row0:row0 + n] = slots[r * slot: r * slot + n]

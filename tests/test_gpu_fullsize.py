@@ -1,6 +1,8 @@
 """BASELINE.json's full sizes on the GPU, through size-independent properties (the oracle would
 take minutes at these sizes): kernels of different design agree bit for bit, shards concatenate
 to the whole, and a random sample is checked against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -88,3 +90,23 @@ def test_c720_l137_shard_with_twelve_resident_boosters():
                 assert torch.equal(first.view(torch.int32), out.view(torch.int32))   # other boosters did not disturb it
     # different months really are different models
     assert not torch.equal(first.view(torch.int32), _predict_dev(torch, boosters[6], rows, "auto").view(torch.int32))
+
+
+def test_two_ranks_share_the_gpu_and_agree_with_one(tmp_path):
+    """Rehearsal of the N > 1 path of bench.py on the one GPU of the box: two ranks (gloo; RCCL refuses two
+    ranks on one device), each predicting its shard of C90 L72 in level-aligned pieces with its own grid
+    offset, asynchronous all-gathers into place; rank 0 then predicts the whole batch in one untiled piece
+    and the two fields must be bit-identical (`--verify`)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OHX_BENCH_SHARE_GPU="1", OHX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for extra in ([], ["--gather-chunks", "1"]):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--grid", "C90", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+                            "--verify"] + extra, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["config"]["verified"] is True and line["n_gpus"] == 2 and line["config"]["grid_hint"] is True
