@@ -366,17 +366,22 @@ void infer_level_size(DMatrixObj& d) {
   DevBuf<uint32_t> d_bad;
   d_cand.upload(cand);
   d_bad.ensure(cand.size());
-  HIP_CHECK(hipMemset(d_bad.p, 0, cand.size() * sizeof(uint32_t)));
-  HIP_CHECK(launch_detect_period(d.d_data, d.nrow, (uint32_t)d.ncol, 0u, d_cand.p, (uint32_t)cand.size(), d_bad.p, nullptr));
+  // LAT is the first column of the OH gather; the last one (SZA) and the 2-D fields in between
+  // (GMISTRATO3, ALBUV, :334-335) serve a caller whose first column is something else
   std::vector<uint32_t> bad(cand.size());
-  HIP_CHECK(hipMemcpy(bad.data(), d_bad.p, bad.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  for (size_t q = 0; q < cand.size(); ++q) {
-    if (bad[q] == 0 && cand[q] <= 0x7FFFFFFFull) {            // the smallest period that holds
-      d.grid_im = (int)cand[q];
-      d.grid_jm = 1;
-      d.grid_row0 = 0;
-      d.grid_inferred = true;
-      return;
+  for (uint32_t col : {0u, (uint32_t)d.ncol - 1u, 21u, 22u}) {
+    if (col >= d.ncol) continue;
+    HIP_CHECK(hipMemset(d_bad.p, 0, cand.size() * sizeof(uint32_t)));
+    HIP_CHECK(launch_detect_period(d.d_data, d.nrow, (uint32_t)d.ncol, col, d_cand.p, (uint32_t)cand.size(), d_bad.p, nullptr));
+    HIP_CHECK(hipMemcpy(bad.data(), d_bad.p, bad.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < cand.size(); ++q) {
+      if (bad[q] == 0 && cand[q] <= 0x7FFFFFFFull) {            // the smallest period that holds
+        d.grid_im = (int)cand[q];
+        d.grid_jm = 1;
+        d.grid_row0 = 0;
+        d.grid_inferred = true;
+        return;
+      }
     }
   }
 }

@@ -375,6 +375,12 @@ def test_level_size_is_inferred_from_the_rows(torch_cuda, small_model):
         got = b.predict(d)
         assert np.array_equal(helpers.bits(got), helpers.bits(helpers.oracle_predict(small_model.image, arr, synth.XX_MISS)))
         d.free()
+    # a caller whose first column is not a 2-D field: another one of the 2-D columns does
+    swapped = wide.copy()
+    swapped[:, [0, 2]] = swapped[:, [2, 0]]                 # T first, LAT third
+    d = capi.DMatrix(swapped, missing=synth.XX_MISS)
+    assert d.grid() == (96 * 72, 1, 0, True)
+    d.free()
     # a matrix over device memory: nothing is looked at on creation, OHXDMatrixInferGrid looks on demand
     t = torch_cuda.from_numpy(wide).cuda()
     dd = capi.DMatrix(device_ptr=t.data_ptr(), nrow=wide.shape[0], ncol=27, missing=synth.XX_MISS)
