@@ -112,7 +112,7 @@ int OHXDeviceCount(int* out);
 /* As XGDMatrixCreateFromMat, but `d_data` already lives in HBM.  The matrix
  * BORROWS the pointer (no copy); it must stay valid until XGDMatrixFree.
  * The inf check of the host path is folded into the predict kernels instead:
- * a predict on data holding +-inf fails. */
+ * a predict on data holding +-inf fails (OHXBoosterCheck reports it). */
 int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong ncol, float missing, DMatrixHandle* out);
 
 /* Optional hint, any DMatrix: its rows are rows row0, row0+1, ... of the gather
@@ -120,25 +120,32 @@ int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong nc
  * (OH_GridCompMod.F90:309-345); row0 > 0 for a rank's contiguous shard.  Predictions do not
  * change.  The kernels then give each wavefront a brick of 4x4x4 (or 8x4x2, 8x8x1) neighbouring
  * gridcells instead of 64 consecutive rows, which measures 1.19x faster on C360 L72 because
- * neighbours in all three directions walk the same tree nodes.  im = jm = 0 withdraws the hint. */
+ * neighbours in all three directions walk the same tree nodes.  im = jm = 0 says "no grid": 64 consecutive
+ * rows per wavefront, and the library does not look for a level size either. */
 int OHXDMatrixSetGrid(DMatrixHandle handle, int im, int jm, bst_ulong row0);
 
-/* What the library knows about the rows of a DMatrix (any pointer may be NULL).  Without a hint,
- * XGDMatrixCreateFromMat looks for the level size by itself: the reference's gather stacks levels and
- * its first column, LAT, is a 2-D field (OH_GridCompMod.F90:313), so that column repeats bit for bit
- * with period im*jm.  A period found that way is reported as im = level size, jm = 1, inferred = 1 and
- * is worth as much as the full hint to within 1 % (runs of 8 cells x 8 levels per wavefront). */
+/* What the library knows about the rows of a DMatrix (any pointer may be NULL).  Without a hint the
+ * library looks for the level size by itself, ONCE per matrix, at the first predict on it: the reference's
+ * gather stacks levels and its first column, LAT, is a 2-D field (OH_GridCompMod.F90:313), so that column
+ * repeats bit for bit with period im*jm.  A period found that way is reported as im = level size, jm = 1,
+ * inferred = 1 and is worth as much as the full hint to within 1 % (runs of 8 cells x 8 levels per
+ * wavefront).  For a matrix the library copied itself (XGDMatrixCreateFromMat) this call looks if nobody
+ * has yet; for a matrix over device memory it reports what is known so far. */
 int OHXDMatrixGetGrid(DMatrixHandle handle, int* im, int* jm, bst_ulong* row0, int* inferred);
 
-/* The same search on demand, for a DMatrix over device memory (OHXDMatrixCreateFromDevice cannot look:
- * the rows need not be there yet).  Waits for `stream`, then looks; *found (may be NULL) says whether a
- * level size was found.  Replaces any earlier hint. */
+/* The same search on demand.  Waits for `stream` (the rows must be there), then looks; *found (may be
+ * NULL) says whether a level size was found.  Replaces any earlier hint.  A device-resident caller that
+ * wants OHXBoosterPredictDevice never to wait calls this (or OHXDMatrixSetGrid) beforehand: the first
+ * predict on a matrix nobody has described waits for its stream once to look. */
 int OHXDMatrixInferGrid(DMatrixHandle handle, void* stream, int* found);
 
 /* Predict straight into device memory: d_out[nrow] margins (or [nrow][ntree]
  * leaf ids with option_mask 16).  `stream` is a hipStream_t (NULL = default
- * stream); the call only enqueues work.  OHXBoosterCheck surfaces errors the
- * kernels raised (inf in the input). */
+ * stream); the call only enqueues work (but see OHXDMatrixInferGrid for the first
+ * predict on an undescribed matrix).  OHXBoosterCheck surfaces errors the
+ * kernels raised (inf in the input).  A booster keeps single scratch buffers
+ * (error flags, Run1 intermediates, staging): calls on ONE booster must not run
+ * concurrently on two streams or threads; different boosters are independent. */
 int OHXBoosterPredictDevice(BoosterHandle handle, DMatrixHandle dmat, int option_mask, unsigned ntree_limit,
                             float* d_out, void* stream);
 int OHXBoosterCheck(BoosterHandle handle, void* stream);
@@ -229,14 +236,11 @@ int OHXSolarGeometryDevice(int jday, const float* d_lats, const float* d_lons, i
  * [7] gather instructions one wavefront issues to walk the whole forest once (super-nodes). */
 int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]);
 
-/* Synthetic inputs of SURVEY.md §8(d), generated in HBM (device pointers):
- * rows [nrows][27] for row_begin..row_begin+nrows of an (im,jm,km) grid, or one
- * MAPL field (feature 0..26 in reference order, PL in Pa; feature -1 = TROPP). */
-int OHXSynthRowsDevice(uint32_t seed, int im, int jm, int km, bst_ulong row_begin, bst_ulong nrows, float* d_out,
-                       void* stream);
-int OHXSynthFieldDevice(uint32_t seed, int feature, int im, int jm, int km, float* d_out, void* stream);
-int OHXInjectMissingDevice(float* d_rows, bst_ulong count, uint32_t seed, uint32_t rate_per_million, float missing,
-                           void* stream);
+/* Returns the device buffers the library keeps between calls to the driver: freed DMatrix storage parked
+ * for the next XGDMatrixCreateFromMat (the reference creates and frees its matrix on every OH tick,
+ * OH_GridCompMod.F90:347,377; at most two buffers are kept; OHX_DMATRIX_POOL=0 in the environment keeps
+ * none).  Live handles are not touched. */
+int OHXReleaseScratch(void);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,7 @@ typedef struct {
   int32_t num_trees;
   OTree* trees;
   char objective[64];
+  int margin_known; /* base_score could be turned into the margin predictions start from */
   float* pred; /* prediction buffer owned by the booster (c_api.cc keeps it thread-local) */
   size_t pred_cap;
 } OBooster;
@@ -96,6 +97,31 @@ static void free_trees(OBooster* b) {
   b->trees = NULL;
   b->num_trees = 0;
   b->loaded = 0;
+}
+
+static int identity_objective(const char* o) {
+  return !strcmp(o, "reg:squarederror") || !strcmp(o, "reg:linear") || !strcmp(o, "reg:squaredlogerror") ||
+         !strcmp(o, "reg:pseudohubererror") || !strcmp(o, "reg:absoluteerror");
+}
+
+/* ObjFunction::ProbToMargin of xgboost 1.6.0 by objective name (regression_loss.h: logistic losses
+   -log(1/p - 1); regression_obj.cu / aft_obj.cu: the log-link objectives log(p); otherwise identity).
+   Returns 0 for a name it does not know. */
+static int prob_to_margin(const char* o, float base_score, float* margin) {
+  if (identity_objective(o) || !strcmp(o, "binary:hinge") || !strncmp(o, "rank:", 5)) {
+    *margin = base_score;
+    return 1;
+  }
+  if (!strcmp(o, "reg:logistic") || !strcmp(o, "binary:logistic") || !strcmp(o, "binary:logitraw")) {
+    *margin = -logf(1.0f / base_score - 1.0f);
+    return base_score > 0.0f && base_score < 1.0f;
+  }
+  if (!strcmp(o, "count:poisson") || !strcmp(o, "reg:gamma") || !strcmp(o, "reg:tweedie") ||
+      !strcmp(o, "survival:cox") || !strcmp(o, "survival:aft")) {
+    *margin = logf(base_score);
+    return 1;
+  }
+  return 0;
 }
 
 /* cursor over the file image */
@@ -146,7 +172,11 @@ static int parse_legacy(OBooster* b, const uint8_t* buf, size_t len) {
   int32_t num_trees;
   memcpy(&num_trees, gp, 4);
   if (num_trees < 0 || num_trees > (1 << 24)) return fail("oracle: bad num_trees");
+  /* learner.cc: margins start from obj->ProbToMargin(base_score) (ConfigureModelParam); a binary file
+     written by xgboost < 1.0 already holds the transformed value (LearnerIO::Load, "old model") */
   b->base_score = mp.base_score;
+  b->margin_known = 1;
+  if (mp.major_version >= 1) b->margin_known = prob_to_margin(b->objective, mp.base_score, &b->base_score);
   b->num_feature = mp.num_feature;
   b->trees = (OTree*)calloc((size_t)(num_trees > 0 ? num_trees : 1), sizeof(OTree));
   b->num_trees = num_trees;
@@ -247,16 +277,28 @@ ORACLE_EXPORT int XGDMatrixCreateFromMat(const float* data, bst_ulong nrow, bst_
   const size_t count = (size_t)nrow * (size_t)ncol;
   if (count && !data) return fail("oracle: data is NULL");
   /* data.cc SparsePage::Push: valid = !(!isinf(missing) && isinf(value)) */
-  if (!isinf(missing))
-    for (size_t i = 0; i < count; ++i)
-      if (isinf(data[i])) return fail("Input data contains `inf` or `nan`");
+  /* libxgboost builds its SparsePage with all threads (data.cc, common::ParallelFor): so does this copy */
+  float* copy = (float*)malloc((count ? count : 1) * sizeof(float));
+  int bad = 0;
+  const int check = !isinf(missing);
+  const int64_t nchunk = (int64_t)((count + 65535) / 65536);
+#pragma omp parallel for schedule(static) reduction(| : bad)
+  for (int64_t c = 0; c < nchunk; ++c) {
+    const size_t lo = (size_t)c * 65536, hi = lo + 65536 < count ? lo + 65536 : count;
+    if (check)
+      for (size_t i = lo; i < hi; ++i) bad |= isinf(data[i]) != 0;
+    memcpy(copy + lo, data + lo, (hi - lo) * sizeof(float));
+  }
+  if (bad) {
+    free(copy);
+    return fail("Input data contains `inf` or `nan`");
+  }
   ODMatrix* d = (ODMatrix*)calloc(1, sizeof *d);
   d->magic = DMAT_MAGIC;
   d->nrow = nrow;
   d->ncol = ncol;
   d->missing = missing;
-  d->data = (float*)malloc((count ? count : 1) * sizeof(float));
-  if (count) memcpy(d->data, data, count * sizeof(float));
+  d->data = copy;
   *out = d;
   return 0;
 }
@@ -357,8 +399,9 @@ ORACLE_EXPORT int XGBoosterPredict(void* h, void* dmat, int option_mask, unsigne
   if (!b->loaded) return fail("oracle: no model loaded");
   if (!out_len || !out_result) return fail("oracle: NULL output argument");
   if (option_mask != 0 && option_mask != 1 && option_mask != 16) return fail("oracle: option_mask not restated");
-  if (option_mask == 0 && strcmp(b->objective, "reg:squarederror") != 0 && strcmp(b->objective, "reg:linear") != 0)
+  if (option_mask == 0 && !identity_objective(b->objective))
     return fail("oracle: only identity objectives are restated");
+  if (option_mask != 16 && !b->margin_known) return fail("oracle: ProbToMargin of this objective is not restated");
   if (d->ncol > b->num_feature) return fail("Number of columns does not match number of features in booster");
   const uint32_t T = (uint32_t)b->num_trees;
   const uint32_t tend = (ntree_limit == 0 || ntree_limit > T) ? T : ntree_limit;

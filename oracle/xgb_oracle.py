@@ -57,7 +57,7 @@ class OracleTree:
 
 @dataclass
 class OracleModel:
-    base_score: np.float32
+    base_score: np.float32   # the margin predictions start from: ProbToMargin(file's base_score)
     num_feature: int
     objective: str
     trees: List[OracleTree] = field(default_factory=list)
@@ -68,6 +68,27 @@ class OracleModel:
 
 
 # --------------------------------------------------------------------- loaders
+
+_IDENTITY = ("reg:squarederror", "reg:linear", "reg:squaredlogerror", "reg:pseudohubererror", "reg:absoluteerror")
+_LOGIT = ("reg:logistic", "binary:logistic", "binary:logitraw")
+_LOG = ("count:poisson", "reg:gamma", "reg:tweedie", "survival:cox", "survival:aft")
+
+
+def prob_to_margin(objective: str, base_score) -> np.float32:
+    """ObjFunction::ProbToMargin of xgboost 1.6.0 by objective name (regression_loss.h: logistic losses
+    -log(1/p - 1); regression_obj.cu / aft_obj.cu: log-link objectives log(p); otherwise identity).
+    learner.cc starts every margin from it (LearnerConfiguration::ConfigureModelParam)."""
+    b = np.float32(base_score)
+    if objective in _IDENTITY or objective == "binary:hinge" or objective.startswith("rank:"):
+        return b
+    if objective in _LOGIT:
+        if not (0.0 < float(b) < 1.0):
+            raise ValueError("base_score must be in (0,1) for logistic loss")
+        return np.float32(-np.log(np.float32(1.0) / b - np.float32(1.0), dtype=np.float32))
+    if objective in _LOG:
+        return np.float32(np.log(b, dtype=np.float32))
+    raise ValueError(f"oracle: ProbToMargin of objective {objective!r} is not restated")
+
 
 def _read_str(buf: bytes, off: int) -> Tuple[str, int]:
     (n,) = struct.unpack_from("<Q", buf, off)
@@ -86,7 +107,9 @@ def load_legacy_binary(buf: bytes) -> OracleModel:
         raise ValueError("oracle: only gbtree is restated")
     (num_trees,) = struct.unpack_from("<i", buf, off)
     off += 160
-    model = OracleModel(np.float32(base_score), int(num_feature), objective)
+    # a binary file written by xgboost < 1.0 already holds the transformed value (LearnerIO::Load)
+    start = np.float32(base_score) if _maj < 1 else prob_to_margin(objective, base_score)
+    model = OracleModel(start, int(num_feature), objective)
     for _ in range(num_trees):
         tp = struct.unpack_from("<37i", buf, off)
         off += 148
@@ -115,8 +138,8 @@ def load_json(text) -> OracleModel:
     gb = learner["gradient_booster"]
     if gb["name"] != "gbtree":
         raise ValueError("oracle: only gbtree is restated")
-    model = OracleModel(np.float32(float(lmp["base_score"])), int(lmp["num_feature"]),
-                        learner["objective"]["name"])
+    model = OracleModel(prob_to_margin(learner["objective"]["name"], float(lmp["base_score"])),
+                        int(lmp["num_feature"]), learner["objective"]["name"])
     for jt in gb["model"]["trees"]:
         model.trees.append(OracleTree(
             cleft=np.asarray(jt["left_children"], dtype=np.int32),
@@ -190,7 +213,8 @@ def load_ubjson(buf: bytes) -> OracleModel:
     doc, _ = _ubj_value(buf, 1, buf[0])
     learner = doc["learner"]
     lmp, gb = learner["learner_model_param"], learner["gradient_booster"]
-    model = OracleModel(np.float32(float(lmp["base_score"])), int(lmp["num_feature"]), learner["objective"]["name"])
+    model = OracleModel(prob_to_margin(learner["objective"]["name"], float(lmp["base_score"])),
+                        int(lmp["num_feature"]), learner["objective"]["name"])
     for jt in gb["model"]["trees"]:
         model.trees.append(OracleTree(
             cleft=np.asarray(jt["left_children"]).astype(np.int32),

@@ -24,8 +24,7 @@ ABI_SYMBOLS = [
     "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXDMatrixInferGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device",
-    "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXSynthRowsDevice",
-    "OHXSynthFieldDevice", "OHXInjectMissingDevice",
+    "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXReleaseScratch",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
 REFERENCE_BOUND_SYMBOLS = [
@@ -109,9 +108,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.OHXSolarGeometry.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp]
     lib.OHXSolarGeometryDevice.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp, vp]
     lib.OHXBoosterGetInfo.argtypes = [vp, C.POINTER(u64)]
-    lib.OHXSynthRowsDevice.argtypes = [u32, i32, i32, i32, u64, u64, vp, vp]
-    lib.OHXSynthFieldDevice.argtypes = [u32, i32, i32, i32, i32, vp, vp]
-    lib.OHXInjectMissingDevice.argtypes = [vp, u64, u32, u32, f32, vp]
+    lib.OHXReleaseScratch.argtypes = []
     if path == LIB_PATH:
         _lib = lib
     return lib

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/ohxgb.h"
@@ -51,8 +52,26 @@ void set_error(const std::string& m) { g_last_error = m; }
     if (e_ != hipSuccess) throw OhxError(std::string(#expr) + " failed: " + hipGetErrorString(e_)); \
   } while (0)
 
-constexpr uint32_t kDMatMagic = 0x4F48444Du;   // "OHDM"
-constexpr uint32_t kBoosterMagic = 0x4F484253u; // "OHBS"
+// Handles are checked against the set of live objects, never by reading the object: the reference frees its
+// DMatrix every step (OH_GridCompMod.F90:377), so a stale handle points at memory the allocator has long
+// handed to someone else.
+struct HandleRegistry {
+  std::mutex mu;
+  std::unordered_set<const void*> live;
+  void add(const void* p) {
+    std::lock_guard<std::mutex> g(mu);
+    live.insert(p);
+  }
+  bool has(const void* p) {
+    std::lock_guard<std::mutex> g(mu);
+    return live.count(p) != 0;
+  }
+  bool remove(const void* p) {
+    std::lock_guard<std::mutex> g(mu);
+    return live.erase(p) != 0;
+  }
+};
+HandleRegistry g_dmats, g_boosters;
 
 // ------------------------------------------------------------------ device
 
@@ -128,17 +147,101 @@ struct PinnedBuf {
 
 // ------------------------------------------------------------------ objects
 
+// Freed matrix buffers are parked here and handed to the next XGDMatrixCreateFromMat that fits: the
+// reference creates and frees its DMatrix on every OH tick (OH_GridCompMod.F90:347,377), and a hipMalloc +
+// hipFree of the whole batch per tick costs more than the prediction of a small sub-domain.  At most
+// kSlots buffers are kept; OHXReleaseScratch() (or OHX_DMATRIX_POOL=0 in the environment) returns them.
+struct RowPool {
+  static constexpr size_t kSlots = 2;
+  struct Slot {
+    float* p;
+    size_t n;
+    int device;
+  };
+  std::mutex mu;
+  std::vector<Slot> slots;
+  bool enabled() const {
+    static const bool on = [] {
+      const char* e = getenv("OHX_DMATRIX_POOL");
+      return !(e && e[0] == '0');
+    }();
+    return on;
+  }
+  // a buffer of at least `count` floats on `device`; *cap = what it really holds
+  float* take(size_t count, int device, size_t* cap) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      size_t best = slots.size();
+      for (size_t i = 0; i < slots.size(); ++i)
+        if (slots[i].device == device && slots[i].n >= count && slots[i].n <= 4 * count + (1u << 18) &&
+            (best == slots.size() || slots[i].n < slots[best].n))
+          best = i;
+      if (best != slots.size()) {
+        Slot sl = slots[best];
+        slots.erase(slots.begin() + (long)best);
+        *cap = sl.n;
+        return sl.p;
+      }
+    }
+    float* p = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(float)));
+    *cap = std::max<size_t>(count, 1);
+    return p;
+  }
+  void give(float* p, size_t cap, int device) {
+    if (p == nullptr) return;
+    if (enabled()) {
+      std::lock_guard<std::mutex> g(mu);
+      slots.push_back({p, cap, device});
+      if (slots.size() <= kSlots) return;
+      size_t drop = 0;                                  // keep the biggest
+      for (size_t i = 1; i < slots.size(); ++i)
+        if (slots[i].n < slots[drop].n) drop = i;
+      p = slots[drop].p;
+      device = slots[drop].device;
+      slots.erase(slots.begin() + (long)drop);
+    }
+    (void)hipFree(p);
+  }
+  void release_all() {
+    std::lock_guard<std::mutex> g(mu);
+    for (Slot& sl : slots) (void)hipFree(sl.p);
+    slots.clear();
+  }
+};
+RowPool g_row_pool;
+
+// Flag and verdict words of the matrix checks (inf scan, level-size search): one device buffer and one pinned
+// host mirror per process, so that a check is launches + ONE read-back.
+struct CheckScratch {
+  std::mutex mu;
+  int device = -1;
+  DevBuf<uint32_t> d;
+  PinnedBuf<uint32_t> h;
+  void ensure(size_t words, int dev) {
+    if (dev != device) {
+      d.release();
+      device = dev;
+    }
+    d.ensure(words);
+    h.ensure(words);
+  }
+};
+CheckScratch g_check;
+
 struct DMatrixObj {
-  uint32_t magic = kDMatMagic;
+  ~DMatrixObj() { g_row_pool.give(owned, owned_cap, device); }
   uint64_t nrow = 0, ncol = 0;
   float missing = NAN;
   const float* d_data = nullptr;  // device
-  DevBuf<float> owned;            // set when the matrix owns its storage
+  float* owned = nullptr;         // set when the matrix owns its storage (XGDMatrixCreateFromMat)
+  size_t owned_cap = 0;
   int device = -1;
   // OHXDMatrixSetGrid: the rows are grid rows grid_row0 .. of an (im,jm,*) grid; 0 = not said
   int grid_im = 0, grid_jm = 0;
   uint64_t grid_row0 = 0;
   bool grid_inferred = false;     // found by infer_level_size, not said by the caller
+  bool grid_looked = false;       // the rows have been searched (or the caller has spoken): do not look again
 };
 
 struct BoosterObj {
@@ -146,9 +249,10 @@ struct BoosterObj {
     if (s_copy) (void)hipStreamDestroy(s_copy);
     if (s_exec) (void)hipStreamDestroy(s_exec);
   }
-  uint32_t magic = kBoosterMagic;
   Forest forest;
   bool loaded = false;
+  float margin_base = 0.0f;        // Forest::margin_base() of the loaded model
+  std::string margin_error;        // why it is unknown (objective this library cannot start a margin for)
   LayoutParams layout;
   std::string kernel_name = "auto";
   int device_pref = -1;
@@ -179,15 +283,13 @@ struct BoosterObj {
 };
 
 DMatrixObj* as_dmat(DMatrixHandle h) {
-  auto* d = static_cast<DMatrixObj*>(h);
-  if (d == nullptr || d->magic != kDMatMagic) throw OhxError("DMatrix handle is invalid or has been freed");
-  return d;
+  if (h == nullptr || !g_dmats.has(h)) throw OhxError("DMatrix handle is invalid or has been freed");
+  return static_cast<DMatrixObj*>(h);
 }
 
 BoosterObj* as_booster(BoosterHandle h) {
-  auto* b = static_cast<BoosterObj*>(h);
-  if (b == nullptr || b->magic != kBoosterMagic) throw OhxError("Booster handle is invalid or has been freed");
-  return b;
+  if (h == nullptr || !g_boosters.has(h)) throw OhxError("Booster handle is invalid or has been freed");
+  return static_cast<BoosterObj*>(h);
 }
 
 KernelKind pick_kernel(const BoosterObj& b) {
@@ -273,7 +375,7 @@ DeviceForest device_forest(const BoosterObj& b) {
   d.super_bytes = (uint32_t)(b.d_super.n * sizeof(SuperNode));
   d.num_trees = (uint32_t)b.forest.trees.size();
   d.num_feature = b.forest.num_feature;
-  d.base_score = b.forest.base_score;
+  d.base_score = b.margin_base;
   return d;
 }
 
@@ -286,6 +388,7 @@ void tree_range(const BoosterObj& b, unsigned ntree_limit, uint32_t* t0, uint32_
 void check_predict_options(const BoosterObj& b, int option_mask, bool* pred_leaf) {
   *pred_leaf = false;
   if (option_mask == 0 || option_mask == 1) {
+    if (!b.margin_error.empty()) throw OhxError(b.margin_error);
     if (option_mask == 0 && !objective_is_identity(b.forest.objective))
       throw OhxError("objective '" + b.forest.objective +
                      "' needs a prediction transform this library does not implement; "
@@ -318,11 +421,78 @@ void raise_flag_errors(BoosterObj& b, hipStream_t stream) {
   }
 }
 
+// A parsed model becomes the booster's: what the readers forgave goes to stderr (as xgboost's LOG(WARNING)
+// does), the margin every prediction starts from is fixed here.
+void adopt_model(BoosterObj& b, Forest&& f) {
+  f.validate();
+  for (const std::string& w : f.warnings) fprintf(stderr, "[libohxgb] warning: model file: %s\n", w.c_str());
+  invalidate_device_state(b);
+  b.forest = std::move(f);
+  b.loaded = true;
+  b.margin_error.clear();
+  try {
+    b.margin_base = b.forest.margin_base();
+  } catch (const OhxError& e) {
+    b.margin_base = b.forest.base_score;
+    b.margin_error = e.what();       // leaf indices (option_mask 16) still work
+  }
+}
+
 bool ends_with(const std::string& s, const std::string& suf) {
   return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
 }
 
-void launch_predict_checked(BoosterObj& b, const DMatrixObj& d, int option_mask, unsigned ntree_limit, float* d_out,
+// A caller that does not say which grid its rows were gathered from (OHXDMatrixSetGrid) - the
+// reference's own call sequence - still shows the size of a level: the gather stacks levels
+// (OH_GridCompMod.F90:309-345) and its first column is a 2-D field (LAT, :313), so that column repeats
+// bit for bit with the level size as period.  Knowing the level size alone the kernels take runs of
+// 8 cells x 8 levels per wave, which measures within 1 % of the full 4x4x4 bricks (34.8 vs 34.6 ms per
+// C360 step; 40.9 ms without).  Speed only: any period gives a valid tiling of the rows.
+// The search runs once per matrix, at its first predict (or OHXDMatrixGetGrid / OHXDMatrixInferGrid), and
+// not at all when the caller has named the grid by then (OHXDMatrixSetGrid).
+constexpr uint64_t kMinLevel = 4096, kMaxLevels = 1024;
+
+uint32_t level_candidates(const DMatrixObj& d) {
+  if (d.ncol < 1 || d.nrow < 2 * kMinLevel) return 0;
+  return (uint32_t)std::min<uint64_t>(kMaxLevels, d.nrow / kMinLevel);       // kmax: candidates k = kmax .. 2
+}
+
+// LAT is the first column of the OH gather; the last one (SZA) and the 2-D fields in between
+// (GMISTRATO3, ALBUV, :334-335) serve a caller whose first column is something else
+PeriodColumns level_columns(const DMatrixObj& d) { return PeriodColumns{{0u, (uint32_t)d.ncol - 1u, 21u, 22u}}; }
+
+// verdict[c * (kmax - 1) + x]: 0 = column c repeats with period nrow / (kmax - x)
+void adopt_level_size(DMatrixObj& d, const uint32_t* verdict, uint32_t kmax) {
+  d.grid_looked = true;
+  for (uint32_t c = 0; c < 4; ++c)
+    for (uint32_t x = 0; x + 1 < kmax; ++x) {                    // ascending periods: the smallest that holds
+      const uint64_t period = d.nrow / (kmax - x);
+      if (verdict[(size_t)c * (kmax - 1) + x] == 0 && period <= 0x7FFFFFFFull) {
+        d.grid_im = (int)period;
+        d.grid_jm = 1;
+        d.grid_row0 = 0;
+        d.grid_inferred = true;
+        return;
+      }
+    }
+}
+
+// Launches + one read-back on `stream`; waits for it (the rows must be there).
+void infer_level_size(DMatrixObj& d, hipStream_t stream) {
+  d.grid_looked = true;
+  const uint32_t kmax = level_candidates(d);
+  if (kmax < 2) return;
+  std::lock_guard<std::mutex> g(g_check.mu);
+  const size_t words = (size_t)4 * (kmax - 1);
+  g_check.ensure(words, d.device);
+  HIP_CHECK(hipMemsetAsync(g_check.d.p, 0, words * sizeof(uint32_t), stream));
+  HIP_CHECK(launch_detect_period(d.d_data, d.nrow, (uint32_t)d.ncol, level_columns(d), 4, kmax, g_check.d.p, stream));
+  HIP_CHECK(hipMemcpyAsync(g_check.h.p, g_check.d.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  adopt_level_size(d, g_check.h.p, kmax);
+}
+
+void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsigned ntree_limit, float* d_out,
                             hipStream_t stream) {
   bool pred_leaf = false;
   check_predict_options(b, option_mask, &pred_leaf);
@@ -332,6 +502,8 @@ void launch_predict_checked(BoosterObj& b, const DMatrixObj& d, int option_mask,
     throw OhxError("the DMatrix lives on HIP device " + std::to_string(d.device) + " but the booster on device " +
                    std::to_string(b.dev.ordinal));
   KernelKind kind = pick_kernel(b);
+  // nobody has said which grid the rows come from: look once (work on `stream` enqueued so far is waited for)
+  if (!d.grid_looked && d.grid_im == 0 && !pred_leaf && kind != KernelKind::Wide) infer_level_size(d, stream);
   if (pred_leaf || kind == KernelKind::Wide) ensure_wide(b);
   PredictArgs a;
   a.rows = d.d_data;
@@ -347,43 +519,6 @@ void launch_predict_checked(BoosterObj& b, const DMatrixObj& d, int option_mask,
   tune.grid_jm = d.grid_jm;
   tune.grid_row0 = d.grid_row0;
   HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, tune));
-}
-
-// A caller that does not say which grid its rows were gathered from (OHXDMatrixSetGrid) - the
-// reference's own call sequence - still shows the size of a level: the gather stacks levels
-// (OH_GridCompMod.F90:309-345) and its first column is a 2-D field (LAT, :313), so that column repeats
-// bit for bit with the level size as period.  Knowing the level size alone the kernels take runs of
-// 8 cells x 8 levels per wave, which measures within 1 % of the full 4x4x4 bricks (34.8 vs 34.6 ms per
-// C360 step; 40.9 ms without).  Speed only: any period gives a valid tiling of the rows.
-void infer_level_size(DMatrixObj& d) {
-  constexpr uint64_t kMinLevel = 4096, kMaxLevels = 1024;
-  if (d.ncol < 1 || d.nrow < 2 * kMinLevel) return;
-  std::vector<uint64_t> cand;
-  for (uint64_t k = std::min<uint64_t>(kMaxLevels, d.nrow / kMinLevel); k >= 2; --k)
-    if (d.nrow % k == 0) cand.push_back(d.nrow / k);        // ascending periods
-  if (cand.empty()) return;
-  DevBuf<uint64_t> d_cand;
-  DevBuf<uint32_t> d_bad;
-  d_cand.upload(cand);
-  d_bad.ensure(cand.size());
-  // LAT is the first column of the OH gather; the last one (SZA) and the 2-D fields in between
-  // (GMISTRATO3, ALBUV, :334-335) serve a caller whose first column is something else
-  std::vector<uint32_t> bad(cand.size());
-  for (uint32_t col : {0u, (uint32_t)d.ncol - 1u, 21u, 22u}) {
-    if (col >= d.ncol) continue;
-    HIP_CHECK(hipMemset(d_bad.p, 0, cand.size() * sizeof(uint32_t)));
-    HIP_CHECK(launch_detect_period(d.d_data, d.nrow, (uint32_t)d.ncol, col, d_cand.p, (uint32_t)cand.size(), d_bad.p, nullptr));
-    HIP_CHECK(hipMemcpy(bad.data(), d_bad.p, bad.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (size_t q = 0; q < cand.size(); ++q) {
-      if (bad[q] == 0 && cand[q] <= 0x7FFFFFFFull) {            // the smallest period that holds
-        d.grid_im = (int)cand[q];
-        d.grid_jm = 1;
-        d.grid_row0 = 0;
-        d.grid_inferred = true;
-        return;
-      }
-    }
-  }
 }
 
 }  // namespace
@@ -413,20 +548,21 @@ int XGDMatrixCreateFromMat(const float* data, bst_ulong nrow, bst_ulong ncol, fl
   d->missing = missing;
   d->device = dev.ordinal;
   const size_t count = (size_t)nrow * (size_t)ncol;
-  d->owned.ensure(count);
-  d->d_data = d->owned.p;
+  d->owned = g_row_pool.take(count, dev.ordinal, &d->owned_cap);
+  d->d_data = d->owned;
   if (count) {
-    HIP_CHECK(hipMemcpy(d->owned.p, data, count * sizeof(float), hipMemcpyHostToDevice));
+    // two waits per call: the copy itself (pageable host memory) and one read-back of the inf flag
+    HIP_CHECK(hipMemcpy(d->owned, data, count * sizeof(float), hipMemcpyHostToDevice));
     // xgboost 1.6.0 (SparsePage::Push): "Input data contains `inf` or `nan`"
-    DevBuf<uint32_t> flag;
-    flag.ensure(1);
-    HIP_CHECK(hipMemset(flag.p, 0, sizeof(uint32_t)));
-    HIP_CHECK(launch_scan_dense(d->owned.p, count, missing, flag.p, nullptr));
-    uint32_t h = 0;
-    HIP_CHECK(hipMemcpy(&h, flag.p, sizeof(h), hipMemcpyDeviceToHost));
-    if (h & kFlagInfInput) throw OhxError("Input data contains `inf` or `nan`");
-    infer_level_size(*d);
+    std::lock_guard<std::mutex> g(g_check.mu);
+    g_check.ensure(1, dev.ordinal);
+    HIP_CHECK(hipMemsetAsync(g_check.d.p, 0, sizeof(uint32_t), nullptr));
+    HIP_CHECK(launch_scan_dense(d->owned, count, missing, g_check.d.p, nullptr));
+    HIP_CHECK(hipMemcpyAsync(g_check.h.p, g_check.d.p, sizeof(uint32_t), hipMemcpyDeviceToHost, nullptr));
+    HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (g_check.h.p[0] & kFlagInfInput) throw OhxError("Input data contains `inf` or `nan`");
   }
+  g_dmats.add(d.get());
   *out = d.release();
   API_END();
 }
@@ -434,6 +570,11 @@ int XGDMatrixCreateFromMat(const float* data, bst_ulong nrow, bst_ulong ncol, fl
 int OHXDMatrixGetGrid(DMatrixHandle handle, int* im, int* jm, bst_ulong* row0, int* inferred) {
   API_BEGIN();
   DMatrixObj* d = as_dmat(handle);
+  // a matrix the library copied itself can be searched whenever it is asked about
+  if (d->owned != nullptr && !d->grid_looked && d->grid_im == 0) {
+    HIP_CHECK(hipSetDevice(d->device));
+    infer_level_size(*d, nullptr);
+  }
   if (im) *im = d->grid_im;
   if (jm) *jm = d->grid_jm;
   if (row0) *row0 = d->grid_row0;
@@ -444,11 +585,11 @@ int OHXDMatrixGetGrid(DMatrixHandle handle, int* im, int* jm, bst_ulong* row0, i
 int OHXDMatrixInferGrid(DMatrixHandle handle, void* stream, int* found) {
   API_BEGIN();
   DMatrixObj* d = as_dmat(handle);
-  HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));   // the rows must be there
+  HIP_CHECK(hipSetDevice(d->device));
   d->grid_im = d->grid_jm = 0;
   d->grid_row0 = 0;
   d->grid_inferred = false;
-  infer_level_size(*d);
+  infer_level_size(*d, static_cast<hipStream_t>(stream));   // waits for `stream`: the rows must be there
   if (found) *found = d->grid_inferred ? 1 : 0;
   API_END();
 }
@@ -464,6 +605,7 @@ int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong nc
   d->missing = missing;
   d->d_data = d_data;
   d->device = dev.ordinal;
+  g_dmats.add(d.get());
   *out = d.release();
   API_END();
 }
@@ -476,14 +618,20 @@ int OHXDMatrixSetGrid(DMatrixHandle handle, int im, int jm, bst_ulong row0) {
   d->grid_jm = jm;
   d->grid_row0 = im ? row0 : 0;
   d->grid_inferred = false;
+  d->grid_looked = true;          // the caller has spoken (0, 0 = "no grid": 64 consecutive rows per wave)
   API_END();
 }
 
 int XGDMatrixFree(DMatrixHandle handle) {
   API_BEGIN();
-  DMatrixObj* d = as_dmat(handle);
-  d->magic = 0;
-  delete d;
+  if (handle == nullptr || !g_dmats.remove(handle)) throw OhxError("DMatrix handle is invalid or has been freed");
+  delete static_cast<DMatrixObj*>(handle);
+  API_END();
+}
+
+int OHXReleaseScratch(void) {
+  API_BEGIN();
+  g_row_pool.release_all();
   API_END();
 }
 
@@ -579,15 +727,17 @@ int XGBoosterCreate(const DMatrixHandle dmats[], bst_ulong len, BoosterHandle* o
   // The reference passes one handle BY VALUE with len == 0 (OH_GridCompMod.F90:255-256):
   // with len == 0 the pointer is not an array and must not be read.
   for (bst_ulong i = 0; i < len; ++i) (void)as_dmat(dmats[i]);
-  *out = new BoosterObj();
+  auto* b = new BoosterObj();
+  g_boosters.add(b);
+  *out = b;
   API_END();
 }
 
 int XGBoosterFree(BoosterHandle handle) {
   API_BEGIN();
   BoosterObj* b = as_booster(handle);
+  if (!g_boosters.remove(handle)) throw OhxError("Booster handle is invalid or has been freed");
   if (b->uploaded) (void)hipSetDevice(b->dev.ordinal);
-  b->magic = 0;
   delete b;
   API_END();
 }
@@ -596,22 +746,14 @@ int XGBoosterLoadModel(BoosterHandle handle, const char* fname) {
   API_BEGIN();
   BoosterObj* b = as_booster(handle);
   if (fname == nullptr) throw OhxError("XGBoosterLoadModel: fname is NULL");
-  Forest f = load_model_file(fname);
-  f.validate();
-  invalidate_device_state(*b);
-  b->forest = std::move(f);
-  b->loaded = true;
+  adopt_model(*b, load_model_file(fname));
   API_END();
 }
 
 int XGBoosterLoadModelFromBuffer(BoosterHandle handle, const void* buf, bst_ulong len) {
   API_BEGIN();
   BoosterObj* b = as_booster(handle);
-  Forest f = load_model_buffer(buf, (size_t)len);
-  f.validate();
-  invalidate_device_state(*b);
-  b->forest = std::move(f);
-  b->loaded = true;
+  adopt_model(*b, load_model_buffer(buf, (size_t)len));
   API_END();
 }
 
@@ -1094,36 +1236,6 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
   info[5] = b->forest.num_feature;
   info[6] = super_used ? 2 : (packed_used ? 1 : 0);
   info[7] = super_used ? super_gathers : 0;
-  API_END();
-}
-
-int OHXSynthRowsDevice(uint32_t seed, int im, int jm, int km, bst_ulong row_begin, bst_ulong nrows, float* d_out,
-                       void* stream) {
-  API_BEGIN();
-  (void)device_count_or_throw();
-  if (d_out == nullptr && nrows) throw OhxError("OHXSynthRowsDevice: d_out is NULL");
-  if (im <= 0 || jm <= 0 || km <= 0) throw OhxError("OHXSynthRowsDevice: bad grid");
-  if (row_begin + nrows > (bst_ulong)im * (bst_ulong)jm * (bst_ulong)km)
-    throw OhxError("OHXSynthRowsDevice: row range exceeds the grid");
-  HIP_CHECK(launch_synth_rows(seed, im, jm, km, row_begin, nrows, d_out, static_cast<hipStream_t>(stream)));
-  API_END();
-}
-
-int OHXSynthFieldDevice(uint32_t seed, int feature, int im, int jm, int km, float* d_out, void* stream) {
-  API_BEGIN();
-  (void)device_count_or_throw();
-  if (d_out == nullptr) throw OhxError("OHXSynthFieldDevice: d_out is NULL");
-  if (im <= 0 || jm <= 0 || km <= 0 || feature < -1 || feature >= 27) throw OhxError("OHXSynthFieldDevice: bad argument");
-  HIP_CHECK(launch_synth_field(seed, feature, im, jm, km, d_out, static_cast<hipStream_t>(stream)));
-  API_END();
-}
-
-int OHXInjectMissingDevice(float* d_rows, bst_ulong count, uint32_t seed, uint32_t rate_per_million, float missing,
-                           void* stream) {
-  API_BEGIN();
-  (void)device_count_or_throw();
-  if (d_rows == nullptr && count) throw OhxError("OHXInjectMissingDevice: d_rows is NULL");
-  HIP_CHECK(launch_inject_missing(d_rows, count, seed, rate_per_million, missing, static_cast<hipStream_t>(stream)));
   API_END();
 }
 

@@ -50,11 +50,20 @@ struct Forest {
   std::vector<int32_t> tree_info;   // output group of each tree
   std::vector<std::pair<std::string, std::string>> attributes;
   std::vector<std::string> metrics;
+  std::string poisson_max_delta_step;   // legacy binary, count:poisson only: one string between attributes and metrics
+  bool legacy_binary = false;           // parsed from the legacy binary format (decides how base_score is read)
+  // what the readers forgave: trailer sections prediction does not need, bookkeeping that disagrees
+  std::vector<std::string> warnings;
 
   size_t total_nodes() const;
   int max_depth() const;
   // Checks every invariant the traversal kernels rely on; throws OhxError.
   void validate() const;
+  // The value a prediction starts from.  xgboost 1.6.0 keeps the user's base_score in the file and starts
+  // margins from obj->ProbToMargin(base_score) (learner.cc, LearnerConfiguration::ConfigureModelParam);
+  // binary files written before 1.0 hold the transformed value already.  Identity for the OH model
+  // (reg:squarederror / reg:linear).  Throws for an objective whose ProbToMargin is not known here.
+  float margin_base() const;
 };
 
 // ---- file formats ----
@@ -75,5 +84,7 @@ std::vector<uint8_t> write_ubjson_model(const Forest& f);
 // Objectives whose prediction transform is the identity (the OH model is
 // reg:squarederror; files written by xgboost < 1.0 call it reg:linear).
 bool objective_is_identity(const std::string& name);
+// obj->ProbToMargin of xgboost 1.6.0 by objective name; false when the name is not known
+bool prob_to_margin(const std::string& objective, float base_score, float* margin);
 
 }  // namespace ohx

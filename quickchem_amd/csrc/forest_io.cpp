@@ -7,6 +7,7 @@
 // there is no model file in the reference tree to check it against.
 #include <algorithm>
 #include <cinttypes>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -66,6 +67,41 @@ int Forest::max_depth() const {
 bool objective_is_identity(const std::string& name) {
   return name == "reg:squarederror" || name == "reg:linear" || name == "reg:squaredlogerror" ||
          name == "reg:pseudohubererror" || name == "reg:absoluteerror";
+}
+
+// src/objective/regression_obj.cu, regression_loss.h, aft_obj.cu, rank_obj.cu, hinge.cu of xgboost 1.6.0:
+// logistic losses return -log(1/p - 1), the log-link objectives log(p), everything else the value itself.
+bool prob_to_margin(const std::string& o, float base_score, float* margin) {
+  if (objective_is_identity(o) || o == "binary:hinge" || o == "rank:pairwise" || o == "rank:ndcg" || o == "rank:map") {
+    *margin = base_score;
+    return true;
+  }
+  if (o == "reg:logistic" || o == "binary:logistic" || o == "binary:logitraw") {
+    if (!(base_score > 0.0f && base_score < 1.0f))
+      throw OhxError("base_score must be in (0,1) for logistic loss, got: " + std::to_string(base_score));
+    *margin = -logf(1.0f / base_score - 1.0f);
+    return true;
+  }
+  if (o == "count:poisson" || o == "reg:gamma" || o == "reg:tweedie" || o == "survival:cox" || o == "survival:aft") {
+    *margin = logf(base_score);
+    return true;
+  }
+  return false;
+}
+
+// JSON/UBJSON hold the user's base_score; a binary file from xgboost < 1.0 holds the margin.  The two are
+// the same number for identity objectives only.
+static void check_base_score_portable(const Forest& f) {
+  if (f.legacy_binary && f.major_version < 1 && !objective_is_identity(f.objective))
+    throw OhxError("a pre-1.0 binary model with objective '" + f.objective + "' cannot be re-saved as JSON/UBJSON");
+}
+
+float Forest::margin_base() const {
+  if (legacy_binary && major_version < 1) return base_score;   // written by xgboost < 1.0: already a margin
+  float m = base_score;
+  if (!prob_to_margin(objective, base_score, &m))
+    throw OhxError("objective '" + objective + "': the margin its base_score stands for is not known to this library");
+  return m;
 }
 
 void Forest::validate() const {
@@ -225,23 +261,39 @@ Forest parse_legacy_binary(const uint8_t* p, size_t len) {
       t.base_weight[(size_t)i] = r.get<float>("node stat");
       t.leaf_child_cnt[(size_t)i] = r.get<int32_t>("node stat");
     }
-    if (deleted != num_deleted) throw OhxError("legacy binary model: num_deleted does not match the node table");
+    // bookkeeping only: which slots are deleted is read from the node table itself
+    if (deleted != num_deleted)
+      f.warnings.push_back("tree " + std::to_string(ti) + ": num_deleted = " + std::to_string(num_deleted) + " but " +
+                           std::to_string(deleted) + " slots of the node table are marked deleted");
   }
   f.tree_info.resize((size_t)num_trees);
   for (int32_t ti = 0; ti < num_trees; ++ti) f.tree_info[(size_t)ti] = r.get<int32_t>("tree_info");
-  if (contain_extra_attrs != 0) {
-    uint64_t n = r.get<uint64_t>("attribute count");
-    if (n > (1u << 20)) throw OhxError("legacy binary model: implausible attribute count");
-    for (uint64_t i = 0; i < n; ++i) {
-      std::string k = r.str("attribute key");
-      std::string v = r.str("attribute value");
-      f.attributes.emplace_back(std::move(k), std::move(v));
+  f.legacy_binary = true;
+  // What follows - attributes, count:poisson's max_delta_step, metric names (learner.cc LearnerIO::Load) -
+  // is not needed to predict: a trailer that does not parse is dropped with a warning, never an error.
+  const size_t trailer = r.off;
+  try {
+    if (contain_extra_attrs != 0) {
+      uint64_t n = r.get<uint64_t>("attribute count");
+      if (n > (1u << 20)) throw OhxError("legacy binary model: implausible attribute count");
+      for (uint64_t i = 0; i < n; ++i) {
+        std::string k = r.str("attribute key");
+        std::string v = r.str("attribute value");
+        f.attributes.emplace_back(std::move(k), std::move(v));
+      }
     }
-  }
-  if (contain_eval_metrics != 0) {
-    uint64_t n = r.get<uint64_t>("metric count");
-    if (n > (1u << 20)) throw OhxError("legacy binary model: implausible metric count");
-    for (uint64_t i = 0; i < n; ++i) f.metrics.push_back(r.str("metric name"));
+    if (f.objective == "count:poisson") f.poisson_max_delta_step = r.str("max_delta_step");
+    if (contain_eval_metrics != 0) {
+      uint64_t n = r.get<uint64_t>("metric count");
+      if (n > (1u << 20)) throw OhxError("legacy binary model: implausible metric count");
+      for (uint64_t i = 0; i < n; ++i) f.metrics.push_back(r.str("metric name"));
+    }
+  } catch (const OhxError& e) {
+    f.attributes.clear();
+    f.metrics.clear();
+    f.poisson_max_delta_step.clear();
+    f.warnings.push_back(std::string("trailer after tree_info ignored (") + e.what() + "), " +
+                         std::to_string(len - trailer) + " bytes");
   }
   return f;
 }
@@ -305,6 +357,7 @@ std::vector<uint8_t> write_legacy_binary(const Forest& f) {
       w.str(kv.second);
     }
   }
+  if (f.objective == "count:poisson") w.str(f.poisson_max_delta_step.empty() ? "0.7" : f.poisson_max_delta_step);
   if (!f.metrics.empty()) {
     w.put<uint64_t>(f.metrics.size());
     for (auto& m : f.metrics) w.str(m);
@@ -547,6 +600,7 @@ Forest parse_ubjson_model(const uint8_t* p, size_t len) {
 }
 
 std::vector<uint8_t> write_ubjson_model(const Forest& f) {
+  check_base_score_portable(f);
   UbjWriter w;
   auto f32 = [&](const std::string& k, const std::vector<float>& v) { w.typed(k, 'd', v, [&](float x) { w.be<float>(x); }); };
   auto i32 = [&](const std::string& k, const std::vector<int32_t>& v) { w.typed(k, 'l', v, [&](int32_t x) { w.be<int32_t>(x); }); };
@@ -709,6 +763,7 @@ static Forest forest_from_document(const json::Value& doc) {
 }
 
 std::string write_json_model(const Forest& f) {
+  check_base_score_portable(f);
   std::string o;
   o.reserve(256 + f.total_nodes() * 96);
   auto fi = [](std::string& s, int32_t v) { s += std::to_string(v); };

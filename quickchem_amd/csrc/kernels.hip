@@ -20,7 +20,6 @@
 #include <cstdint>
 
 #include "kernels.hpp"
-#include "synth_common.h"
 
 namespace ohx {
 
@@ -548,26 +547,38 @@ __global__ __launch_bounds__(kBlock) void scan_dense_kernel(const float* __restr
   if (any_inf && !is_inf(missing)) atomicOr(flags, kFlagInfInput);
 }
 
-// Is column `col` of the row-major matrix periodic in the rows with period cand[b]?  One block per
-// candidate period, 4 x blockDim sampled row pairs each, bit-for-bit.  This is how a matrix gathered
+// Is a column of the row-major matrix periodic in the rows with period nrow / k?  blockIdx.x picks k
+// (kmax - blockIdx.x, so ascending periods; a k that does not divide nrow is marked 2 = "no candidate"),
+// blockIdx.y the column; 4 x blockDim sampled row pairs each, bit for bit.  This is how a matrix gathered
 // level by level from a grid shows its level size without being told: a 2-D field (LAT, feature 0 of
 // the OH gather, OH_GridCompMod.F90:313) repeats exactly from one level to the next.
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
 __global__ __launch_bounds__(kBlock) void detect_period_kernel(const float* __restrict__ data, uint64_t nrow,
-                                                               uint32_t ncol, uint32_t col,
-                                                               const uint64_t* __restrict__ cand,
-                                                               uint32_t* __restrict__ mismatch) {
-  const uint64_t period = cand[blockIdx.x];
+                                                               uint32_t ncol, PeriodColumns cols, uint32_t kmax,
+                                                               uint32_t* __restrict__ verdict) {
+  const uint32_t k = kmax - blockIdx.x;
+  uint32_t* slot = verdict + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const uint32_t col = cols.col[blockIdx.y];
+  if (nrow % k != 0 || col >= ncol) {
+    if (threadIdx.x == 0) *slot = 2u;
+    return;
+  }
+  const uint64_t period = nrow / k;
   const uint64_t span = nrow - period;
   const uint32_t* bits = reinterpret_cast<const uint32_t*>(data);
   bool bad = false;
   for (uint32_t s = threadIdx.x; s < 4u * blockDim.x; s += blockDim.x) {
-    const uint64_t m = ((uint64_t)ohx_hash4(0x5eedu, s, blockIdx.x, 0u, 0u) * 2654435761ull + s) % span;
+    const uint64_t m = ((uint64_t)mix32(mix32(0x5eedu ^ s) ^ blockIdx.x) * 2654435761ull + s) % span;
     bad |= bits[m * ncol + col] != bits[(m + period) * ncol + col];
   }
   // the first and the last pair as well
   if (threadIdx.x == 0) bad |= bits[col] != bits[period * ncol + col] ||
                                bits[(span - 1) * ncol + col] != bits[(nrow - 1) * ncol + col];
-  if (bad) atomicOr(&mismatch[blockIdx.x], 1u);
+  if (bad) atomicOr(slot, 1u);
 }
 
 // ------------------------------------------------------------------ OH Run1: before and after the predict
@@ -693,57 +704,6 @@ __global__ __launch_bounds__(kBlock) void solar_geometry_kernel(SolarArgs a) {
     cosz = fminf(1.0f, cosz);
     cosz = fmaxf(-1.0f, cosz);
     a.sza_noon[m] = acosf(cosz) * a.rad2deg;
-  }
-}
-
-// ------------------------------------------------------------------ synthetic inputs
-
-__global__ __launch_bounds__(kBlock) void synth_rows_kernel(uint32_t seed, int im, int jm, int km, uint64_t row_begin,
-                                                            uint64_t nrows, float* __restrict__ out) {
-  // one thread per (row, feature): consecutive threads write consecutive floats
-  const uint64_t total = nrows * OHX_NFEAT;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t plane = (uint64_t)im * (uint64_t)jm;
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const uint64_t r = e / OHX_NFEAT;
-    const int f = (int)(e - r * OHX_NFEAT);
-    const uint64_t m = row_begin + r;
-    const int k = (int)(m / plane);
-    const uint64_t c = m - (uint64_t)k * plane;
-    const int j = (int)(c / (uint64_t)im);
-    const int i = (int)(c - (uint64_t)j * (uint64_t)im);
-    out[e] = ohx_synth_feature(seed, f, i, j, k, im, jm, km);
-  }
-}
-
-// feature >= 0: that feature as a MAPL field ((im,jm) or (im,jm,km); PL in Pa);
-// feature == -1: TROPP (im,jm) in Pa
-__global__ __launch_bounds__(kBlock) void synth_field_kernel(uint32_t seed, int feature, int im, int jm, int km,
-                                                             float* __restrict__ out) {
-  const uint64_t plane = (uint64_t)im * (uint64_t)jm;
-  const bool two_d = feature < 0 || ohx_feature_is_2d(feature);
-  const uint64_t total = two_d ? plane : plane * (uint64_t)km;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += stride) {
-    const int k = (int)(m / plane);
-    const uint64_t c = m - (uint64_t)k * plane;
-    const int j = (int)(c / (uint64_t)im);
-    const int i = (int)(c - (uint64_t)j * (uint64_t)im);
-    float v;
-    if (feature < 0) v = ohx_synth_tropp_pa(seed, i, j);
-    else if (feature == OHX_F_PL) v = ohx_synth_pl_pa(seed, i, j, k, im, jm, km);
-    else v = ohx_synth_feature(seed, feature, i, j, k, im, jm, km);
-    out[m] = v;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void inject_missing_kernel(float* __restrict__ rows, uint64_t count, uint32_t seed,
-                                                                uint32_t rate_per_million, float missing) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const float qnan = __builtin_nanf("");
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
-    const uint32_t h = ohx_hash4(seed, 0x99000000u, (uint32_t)(e & 0xFFFFFFFFu), (uint32_t)(e >> 32), 0u);
-    if (h % 1000000u < rate_per_million) rows[e] = (h & 0x80000000u) ? missing : qnan;
   }
 }
 
@@ -971,37 +931,11 @@ hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, u
   return hipGetLastError();
 }
 
-hipError_t launch_detect_period(const float* data, uint64_t nrow, uint32_t ncol, uint32_t col, const uint64_t* d_cand,
-                                uint32_t ncand, uint32_t* d_mismatch, hipStream_t stream) {
-  if (ncand == 0) return hipSuccess;
-  hipLaunchKernelGGL(detect_period_kernel, dim3(ncand), dim3(kBlock), 0, stream, data, nrow, ncol, col, d_cand,
-                     d_mismatch);
-  return hipGetLastError();
-}
-
-hipError_t launch_synth_rows(uint32_t seed, int im, int jm, int km, uint64_t row_begin, uint64_t nrows, float* out,
-                             hipStream_t stream) {
-  if (nrows == 0) return hipSuccess;
-  hipLaunchKernelGGL(synth_rows_kernel, dim3(grid_for(nrows * OHX_NFEAT, 256, 16)), dim3(kBlock), 0, stream, seed, im,
-                     jm, km, row_begin, nrows, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_synth_field(uint32_t seed, int feature, int im, int jm, int km, float* out, hipStream_t stream) {
-  const uint64_t plane = (uint64_t)im * (uint64_t)jm;
-  const bool two_d = feature < 0 || ohx_feature_is_2d(feature);
-  const uint64_t total = two_d ? plane : plane * (uint64_t)km;
-  if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(synth_field_kernel, dim3(grid_for(total, 256, 16)), dim3(kBlock), 0, stream, seed, feature, im,
-                     jm, km, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_inject_missing(float* rows, uint64_t count, uint32_t seed, uint32_t rate_per_million, float missing,
-                                 hipStream_t stream) {
-  if (count == 0) return hipSuccess;
-  hipLaunchKernelGGL(inject_missing_kernel, dim3(grid_for(count, 256, 16)), dim3(kBlock), 0, stream, rows, count, seed,
-                     rate_per_million, missing);
+hipError_t launch_detect_period(const float* data, uint64_t nrow, uint32_t ncol, const PeriodColumns& cols,
+                                uint32_t ncols, uint32_t kmax, uint32_t* d_verdict, hipStream_t stream) {
+  if (kmax < 2 || ncols == 0) return hipSuccess;
+  hipLaunchKernelGGL(detect_period_kernel, dim3(kmax - 1, ncols), dim3(kBlock), 0, stream, data, nrow, ncol, cols, kmax,
+                     d_verdict);
   return hipGetLastError();
 }
 

@@ -179,15 +179,13 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& forest, const Pre
 hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& forest, const FieldsArgs& a, int num_cus,
                                  hipStream_t stream, const LaunchTuning& tune = LaunchTuning());
 hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream);
-// d_mismatch[c] != 0 afterwards <=> column `col` is NOT periodic with period d_cand[c] (sampled); all device pointers
-hipError_t launch_detect_period(const float* data, uint64_t nrow, uint32_t ncol, uint32_t col, const uint64_t* d_cand,
-                                uint32_t ncand, uint32_t* d_mismatch, hipStream_t stream);
-
-// synthetic inputs (synth_common.h), generated in HBM
-hipError_t launch_synth_rows(uint32_t seed, int im, int jm, int km, uint64_t row_begin, uint64_t nrows, float* out,
-                             hipStream_t stream);
-hipError_t launch_synth_field(uint32_t seed, int feature, int im, int jm, int km, float* out, hipStream_t stream);
-hipError_t launch_inject_missing(float* rows, uint64_t count, uint32_t seed, uint32_t rate_per_million, float missing,
-                                 hipStream_t stream);
+// Level-size search (capi.cpp infer_level_size): block (x, y) tests whether column cols.col[y] repeats with
+// period nrow / (kmax - x); d_verdict[y * (kmax - 1) + x] must be zero before and is 0 (periodic), 1 (not) or
+// 2 (kmax - x does not divide nrow) afterwards.  All device pointers.
+struct PeriodColumns {
+  uint32_t col[4];
+};
+hipError_t launch_detect_period(const float* data, uint64_t nrow, uint32_t ncol, const PeriodColumns& cols,
+                                uint32_t ncols, uint32_t kmax, uint32_t* d_verdict, hipStream_t stream);
 
 }  // namespace ohx

@@ -2,8 +2,9 @@
 
 The reference ships neither data nor a model (its models sit on NCCS paths,
 ``OH_GridComp/OH_instance_OH.rc:17-20``), so tests and the benchmark draw both from
-``libohx_synth.so`` (host, g++) and from the device generator in ``libohxgb.so``;
-both compile the same ``csrc/synth_common.h`` and agree bit for bit.
+``libohx_synth.so`` (host, g++) and ``libohx_synth_gpu.so`` (the same generator in HBM, hipcc);
+both compile the same ``csrc/synth_common.h`` and agree bit for bit.  Neither is part of
+the product library.
 """
 from __future__ import annotations
 
@@ -18,6 +19,7 @@ from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SYNTH_LIB_PATH = os.path.join(_HERE, "lib", "libohx_synth.so")
+SYNTH_GPU_LIB_PATH = os.path.join(_HERE, "lib", "libohx_synth_gpu.so")
 
 FEATURE_SEED = 20241108
 MODEL_SEED = 1060
@@ -154,24 +156,44 @@ def super_walk_cpu(image, rows: np.ndarray, missing: float = XX_MISS):
     return out, {"super_nodes": int(info[0]), "phase1_trees": int(info[1]), "steps": int(info[2])}
 
 
-# ---- device generators (torch tensors in HBM; libohxgb.so) ----
+# ---- device generators (torch tensors in HBM; libohx_synth_gpu.so, test support like the rest of this file) ----
+
+_gpu_lib = None
+
+
+def _load_gpu():
+    global _gpu_lib
+    if _gpu_lib is None:
+        if not os.path.exists(SYNTH_GPU_LIB_PATH):
+            raise capi.OhxError(f"{SYNTH_GPU_LIB_PATH} is missing: run __graft_entry__.build()")
+        lib = C.CDLL(SYNTH_GPU_LIB_PATH)
+        vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+        lib.ohx_synth_gpu_last_error.restype = C.c_char_p
+        lib.ohx_synth_rows_device.argtypes = [u32, i32, i32, i32, u64, u64, vp, vp]
+        lib.ohx_synth_field_device.argtypes = [u32, i32, i32, i32, i32, vp, vp]
+        lib.ohx_inject_missing_device.argtypes = [vp, u64, u32, u32, C.c_float, vp]
+        _gpu_lib = lib
+    return _gpu_lib
+
+
+def _check_gpu(rc: int) -> None:
+    if rc != 0:
+        raise capi.OhxError(_load_gpu().ohx_synth_gpu_last_error().decode())
+
 
 def rows_device(grid: Tuple[int, int, int], row_begin: int, nrows: int, out, seed: int = FEATURE_SEED,
                 stream: int = 0) -> None:
     """Fill torch tensor `out` ([nrows][27] float32, on the GPU) with rows row_begin.."""
-    lib = capi.load_library()
     im, jm, km = grid
     assert out.is_contiguous() and out.numel() == nrows * NFEAT
-    capi.check(lib, lib.OHXSynthRowsDevice(seed, im, jm, km, row_begin, nrows, out.data_ptr(), stream or None))
+    _check_gpu(_load_gpu().ohx_synth_rows_device(seed, im, jm, km, row_begin, nrows, out.data_ptr(), stream or None))
 
 
 def field_device(grid: Tuple[int, int, int], feature: int, out, seed: int = FEATURE_SEED, stream: int = 0) -> None:
-    lib = capi.load_library()
     im, jm, km = grid
-    capi.check(lib, lib.OHXSynthFieldDevice(seed, feature, im, jm, km, out.data_ptr(), stream or None))
+    _check_gpu(_load_gpu().ohx_synth_field_device(seed, feature, im, jm, km, out.data_ptr(), stream or None))
 
 
 def inject_missing_device(rows, rate_per_million: int, missing: float = XX_MISS, seed: int = 7, stream: int = 0) -> None:
-    lib = capi.load_library()
-    capi.check(lib, lib.OHXInjectMissingDevice(rows.data_ptr(), rows.numel(), seed, rate_per_million, missing,
-                                               stream or None))
+    _check_gpu(_load_gpu().ohx_inject_missing_device(rows.data_ptr(), rows.numel(), seed, rate_per_million, missing,
+                                                     stream or None))

@@ -22,7 +22,7 @@ _oracle = None
 
 
 def ensure_built():
-    need = [ORACLE_SO, PRODUCT_SO, SYNTH_SO, DRIVER_HIP, DRIVER_ORACLE]
+    need = [ORACLE_SO, PRODUCT_SO, SYNTH_SO, SYNTH_SO.replace("libohx_synth.so", "libohx_synth_gpu.so"), DRIVER_HIP, DRIVER_ORACLE]
     if all(os.path.exists(p) for p in need):
         return
     sys.path.insert(0, ROOT)
@@ -191,3 +191,58 @@ def read_run1_output(path, im, jm, km):
     out = [np.ascontiguousarray(np.frombuffer(raw, dtype="<f4", count=n, offset=12 + 4 * n * q)
                                 .reshape(km, jm, im).transpose(2, 1, 0)) for q in range(3)]
     return rc, k1, k2, out[0], out[1], out[2]
+
+
+def legacy_image(doc, *, version=(1, 6), binf=False, attributes=None, metrics=None, objective=None,
+                 max_delta_step=None, trailer=None, num_deleted_lie=0, base_score=None):
+    """An XGBoost legacy-binary model image written HERE, field by field, from a document in XGBoost's JSON
+    schema - independent of the product's writer (csrc/forest_io.cpp) and of both oracles' readers.  Layout as
+    published for xgboost 1.6.0: LearnerModelParamLegacy (136 B), objective and booster
+    names (uint64 length + bytes), GBTreeModelParam (160 B), per tree TreeParam (148 B) + num_nodes x Node
+    (20 B) + num_nodes x RTreeNodeStat (16 B), tree_info, then - in this order, learner.cc LearnerIO::Save -
+    attributes, count:poisson's max_delta_step, metric names.  `version=(0, 0)` is what xgboost < 1.0 wrote
+    (the reference's XGBoost_0.81_File, OH_instance_OH.rc:18): those words were still `reserved`."""
+    learner = doc["learner"]
+    lmp = learner["learner_model_param"]
+    trees = learner["gradient_booster"]["model"]["trees"]
+    obj = (objective or learner["objective"]["name"]).encode()
+    attributes = attributes or []
+    metrics = metrics or []
+
+    def s(b):
+        return struct.pack("<Q", len(b)) + b
+    out = bytearray(b"binf" if binf else b"")
+    out += struct.pack("<fIiiiIII", float(lmp["base_score"]) if base_score is None else base_score,
+                       int(lmp["num_feature"]), int(lmp["num_class"]), 1 if attributes else 0, 1 if metrics else 0,
+                       version[0], version[1], 1 if version[0] >= 1 else 0) + bytes(26 * 4)
+    out += s(obj) + s(b"gbtree")
+    out += struct.pack("<iiiiqii", len(trees), 1, int(lmp["num_feature"]), 0, 0, 1, 0) + bytes(32 * 4)
+    for t in trees:
+        n = len(t["left_children"])
+        deleted = [int(x) == 0xFFFFFFFF for x in t["split_indices"]]
+        out += struct.pack("<6i", 1, n, sum(deleted[1:]) + num_deleted_lie, 0, int(t["tree_param"]["num_feature"]), 0)
+        out += bytes(31 * 4)
+        is_left = {int(c): True for c in t["left_children"] if c != -1}
+        for i in range(n):
+            par = int(t["parents"][i])
+            parent = -1 if par == 2147483647 else (par | (0x80000000 if is_left.get(i) else 0))
+            sindex = 0xFFFFFFFF if deleted[i] else (int(t["split_indices"][i]) | (int(t["default_left"][i]) << 31))
+            out += struct.pack("<IiiIf", parent & 0xFFFFFFFF, int(t["left_children"][i]), int(t["right_children"][i]),
+                               sindex, float(t["split_conditions"][i]))
+        for i in range(n):
+            out += struct.pack("<fffi", float(t["loss_changes"][i]), float(t["sum_hessian"][i]),
+                               float(t["base_weights"][i]), 0)
+    out += struct.pack(f"<{len(trees)}i", *[0] * len(trees))
+    if trailer is not None:
+        return bytes(out + trailer)
+    if attributes:
+        out += struct.pack("<Q", len(attributes))
+        for k, v in attributes:
+            out += s(k.encode()) + s(v.encode())
+    if obj == b"count:poisson":
+        out += s((max_delta_step or "0.7").encode())
+    if metrics:
+        out += struct.pack("<Q", len(metrics))
+        for m in metrics:
+            out += s(m.encode())
+    return bytes(out)

@@ -59,7 +59,47 @@ def test_handle_misuse_is_an_error_not_a_crash():
     b = capi.Booster()
     h = b.handle
     b.free()
-    assert lib.XGBoosterFree(h) == -1          # double free is caught by the magic word
+    assert lib.XGBoosterFree(h) == -1          # double free: the handle is no longer in the live table
+    junk = C.create_string_buffer(b"\x4f" * 256)
+    assert lib.XGBoosterFree(C.cast(junk, C.c_void_p)) == -1 and lib.XGDMatrixFree(C.cast(junk, C.c_void_p)) == -1
+
+
+def test_the_product_library_exports_the_header_and_nothing_else():
+    """No benchmark-input generators, no test hooks: the dynamic symbol table of libohxgb.so is include/ohxgb.h."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", helpers.PRODUCT_SO], stdout=subprocess.PIPE, text=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+    assert exported == header_symbols()
+
+
+def test_stale_handles_under_address_sanitizer(tmp_path):
+    """tools/handle_abuse.c against an AddressSanitizer build of the library's host side (device code
+    unsanitised; no GPU needed): double frees, handles whose block the allocator has recycled, pointers that
+    never were handles - each refused with -1, none of them read."""
+    import shutil
+    import subprocess
+    hipcc, clang = "/opt/rocm/bin/hipcc", "/opt/rocm/lib/llvm/bin/clang"
+    if not (os.path.exists(hipcc) and os.path.exists(clang)):
+        pytest.skip("no ROCm toolchain")
+    rt = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        pytest.skip("this clang has no shared AddressSanitizer runtime")
+    src = os.path.join(helpers.ROOT, "quickchem_amd", "csrc")
+    lib = tmp_path / "libohxgb_asan.so"
+    r = subprocess.run([hipcc, "-O1", "-g", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+                        "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-x", "hip",
+                        os.path.join(src, "capi.cpp"), os.path.join(src, "kernels.hip"), "-x", "c++",
+                        os.path.join(src, "forest_io.cpp"), os.path.join(src, "flatten.cpp"), "-shared", "-o", str(lib)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exe = tmp_path / "handle_abuse"
+    r = subprocess.run([clang, "-g", "-fsanitize=address", "-shared-libsan", os.path.join(helpers.ROOT, "tools", "handle_abuse.c"),
+                        f"-L{tmp_path}", "-lohxgb_asan", f"-Wl,-rpath,{tmp_path}", f"-Wl,-rpath,{os.path.dirname(rt)}",
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "handle_abuse: ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
 def test_compute_without_gpu_fails_loudly():

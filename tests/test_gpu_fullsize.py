@@ -63,6 +63,57 @@ def test_full_size_properties(full_model, gridname, shard):
     assert torch.isfinite(a).all() and -16 < float(a.min()) and float(a.max()) < -10
 
 
+def _hinted_vs_unhinted(torch, model, grid, row0, n, how):
+    """The shipped default (super-nodes, bricks from the grid hint or from the inferred level size) against the
+    `wide` kernel on the same rows without any hint (64 consecutive rows per wave, another node format), plus
+    50 000 random rows against the oracle."""
+    rows = torch.empty((n, 27), dtype=torch.float32, device="cuda")
+    synth.rows_device(grid, row0, n, rows)
+    booster = capi.Booster(model_buffer=model.image)
+    d = capi.DMatrix(device_ptr=rows.data_ptr(), nrow=n, ncol=27, missing=synth.XX_MISS)
+    if how == "hint":
+        d.set_grid(grid[0], grid[1], row0)
+        assert d.grid() == (grid[0], grid[1], row0, False)
+    elif how == "infer":
+        assert d.infer_grid() is True
+        assert d.grid() == (grid[0] * grid[1], 1, 0, True)
+    out = torch.empty(n, dtype=torch.float32, device="cuda")
+    booster.predict_device(d, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    booster.check()
+    if how == "lazy":               # nobody described the rows: the first predict looked for the level size
+        assert d.grid() == (grid[0] * grid[1], 1, 0, True)
+    d.free()
+    ref = _predict_dev(torch, capi.Booster(model_buffer=model.image), rows, "wide")
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    idx = torch.randint(0, n, (50_000,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    want = helpers.oracle_predict(model.image, rows[idx].cpu().numpy(), synth.XX_MISS)
+    assert np.array_equal(helpers.bits(out[idx].cpu().numpy()), helpers.bits(want))
+    return out
+
+
+@pytest.mark.parametrize("how", ["hint", "infer", "lazy"])
+def test_whole_c360_batch_with_the_default_tiling(full_model, how):
+    """The headline workload exactly as bench.py times it: all 55 987 200 rows of C360 L72 in ONE DMatrix,
+    4x4x4 bricks from OHXDMatrixSetGrid(360, 2160, 0) - 32-bit brick numbering, 874 800 tiles, a train of 86
+    launches; with the level size inferred (8 cells x 8 levels per wave); and with nothing said at all
+    ("lazy": OHXBoosterPredictDevice looks for the level size itself at the first predict)."""
+    import torch
+    torch.cuda.set_device(0)
+    grid = synth.GRIDS["C360"]
+    _hinted_vs_unhinted(torch, full_model, grid, 0, grid[0] * grid[1] * grid[2], how)
+
+
+def test_c720_l137_shard_starting_inside_a_level(full_model):
+    """Config #5 with the hint and a ragged start: one eighth of C720 L137 whose first row is 12 345 cells into
+    a level (row0 not a multiple of im*jm), so the first and last bricks overhang the row range."""
+    import torch
+    torch.cuda.set_device(0)
+    grid = synth.GRIDS["C720L137"]
+    n = grid[0] * grid[1] * grid[2] // 8
+    _hinted_vs_unhinted(torch, full_model, grid, 5 * n + 12_345, n, "hint")
+
+
 def test_c720_l137_shard_with_twelve_resident_boosters():
     """BASELINE.json config #5: one of the 8 row shards of C720 L137 (53 265 600 gridcells, 5.75 GB of
     features) with twelve monthly boosters resident in HBM at once (the reference keeps one booster per

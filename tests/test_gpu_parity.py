@@ -392,7 +392,60 @@ def test_level_size_is_inferred_from_the_rows(torch_cuda, small_model):
     b.check()
     assert np.array_equal(helpers.bits(out.cpu().numpy()), helpers.bits(want))
     dd.free()
+    # ... and the first predict on a matrix nobody described looks by itself, once
+    dd = capi.DMatrix(device_ptr=t.data_ptr(), nrow=wide.shape[0], ncol=27, missing=synth.XX_MISS)
+    out.zero_()
+    b.predict_device(dd, out.data_ptr())
+    torch_cuda.cuda.synchronize()
+    assert dd.grid() == (96 * 72, 1, 0, True)
+    assert np.array_equal(helpers.bits(out.cpu().numpy()), helpers.bits(want))
+    dd.set_grid(0, 0, 0)                     # "no grid" is an answer too: 64 consecutive rows, no further look
+    b.predict_device(dd, out.data_ptr())
+    torch_cuda.cuda.synchronize()
+    assert dd.grid() == (0, 0, 0, False)
+    assert np.array_equal(helpers.bits(out.cpu().numpy()), helpers.bits(want))
+    dd.free()
+    # the reference frees and re-creates its matrix every tick: the parked buffer is reused, results unchanged
+    for _ in range(3):
+        d = capi.DMatrix(wide, missing=synth.XX_MISS)
+        assert np.array_equal(helpers.bits(b.predict(d)), helpers.bits(want))
+        d.free()
+    small = capi.DMatrix(wide[:7], missing=synth.XX_MISS)       # a tiny matrix does not take the big parked buffer
+    assert np.array_equal(helpers.bits(b.predict(small)), helpers.bits(want[:7]))
+    small.free()
+    assert b.lib.OHXReleaseScratch() == 0
     # too small to bother (fewer than 2 x 4096 rows)
     d = capi.DMatrix(wide[:5000], missing=synth.XX_MISS)
     assert d.grid() == (0, 0, 0, False)
     d.free()
+
+
+def test_margin_of_a_non_identity_objective_starts_from_prob_to_margin(torch_cuda):
+    """option_mask = 1 on a logistic / log-link model: xgboost starts the margin from
+    obj->ProbToMargin(base_score), not from base_score; the transformed value (option_mask = 0)
+    is not implemented and is refused, never returned untransformed."""
+    import json as _json
+    from oracle import xgb_oracle as O
+    doc = _json.load(open(os.path.join(helpers.GOLDEN, "hand_forest.json")))
+    cases, rows = helpers.load_hand_cases()
+    for objective, base in (("binary:logistic", 0.25), ("count:poisson", 0.5), ("reg:squarederror", 0.5)):
+        doc["learner"]["objective"]["name"] = objective
+        doc["learner"]["learner_model_param"]["base_score"] = repr(base)
+        text = _json.dumps(doc).encode()
+        want = O.predict(O.load_model(text), rows, missing=cases["missing"])
+        for kernel in ("wide", "packed2", "super2"):
+            got = gpu_predict(text, rows, cases["missing"], kernel, option_mask=1)
+            assert np.array_equal(helpers.bits(got), helpers.bits(want)), (objective, kernel)
+        if objective != "reg:squarederror":
+            with pytest.raises(capi.OhxError, match="prediction transform"):
+                gpu_predict(text, rows, cases["missing"], "super2", option_mask=0)
+            img = helpers.legacy_image(doc, version=(0, 0))           # pre-1.0 binary: the margin as stored
+            got = gpu_predict(img, rows, cases["missing"], "super2", option_mask=1)
+            m = O.load_model(img)
+            assert float(m.base_score) == base
+            assert np.array_equal(helpers.bits(got), helpers.bits(O.predict(m, rows, missing=cases["missing"])))
+    doc["learner"]["objective"]["name"] = "my:custom"
+    with pytest.raises(capi.OhxError, match="not known"):
+        gpu_predict(_json.dumps(doc).encode(), rows, cases["missing"], "super2", option_mask=1)
+    leaves = gpu_predict(_json.dumps(doc).encode(), rows, cases["missing"], "wide", option_mask=16)
+    assert np.array_equal(leaves.reshape(len(rows), -1), np.float32(cases["leaf_index"]))

@@ -188,3 +188,101 @@ def test_model_readers_survive_mutated_files_under_sanitizers(tmp_path, small_mo
     for seed in (11, 12):
         r = subprocess.run([str(exe), str(model), "4000", str(seed)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "0 crashes" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def _hand_doc():
+    return json.load(open(os.path.join(helpers.GOLDEN, "hand_forest.json")))
+
+
+def _trees_of(image):
+    doc = json.loads(synth.convert_model(np.frombuffer(image, dtype=np.uint8), "json").tobytes())
+    return doc, doc["learner"]["gradient_booster"]["model"]["trees"]
+
+
+@pytest.mark.parametrize("variant", ["v16_plain", "v16_binf_attrs_metrics", "v081_bin"])
+def test_legacy_files_from_an_independent_writer(variant):
+    """The production models are legacy-binary files written by XGBoost 1.6.0 (".model") and by 0.81 (".bin")
+    (OH_instance_OH.rc:17-20).  No such file exists here, so the layout is written a third time, in
+    tests/helpers.legacy_image, straight from the published structs; the product's reader and the C oracle's
+    must both read it, and the hand-computed answers of tests/golden/hand_cases.json must come out."""
+    doc = _hand_doc()
+    kw = {"v16_plain": dict(version=(1, 6)),
+          "v16_binf_attrs_metrics": dict(version=(1, 6), binf=True, attributes=[("best_iteration", "99"), ("a", "")],
+                                         metrics=["rmse", "mae"]),
+          "v081_bin": dict(version=(0, 0), objective="reg:linear")}[variant]
+    img = helpers.legacy_image(doc, **kw)
+    cases, rows = helpers.load_hand_cases()
+    got = helpers.oracle_predict(np.frombuffer(img, dtype=np.uint8), rows, cases["missing"])
+    assert np.array_equal(got, np.float32(cases["margin"]))
+    out, trees = _trees_of(img)
+    want = doc["learner"]["gradient_booster"]["model"]["trees"]
+    for a, b in zip(trees, want):
+        for key in ("left_children", "right_children", "split_indices", "default_left", "parents"):
+            assert [int(x) for x in a[key]] == [int(x) for x in b[key]], key
+        assert np.array_equal(np.float32(a["split_conditions"]), np.float32(b["split_conditions"]))
+    assert out["learner"]["objective"]["name"] == kw.get("objective", "reg:squarederror")
+    if "attributes" in kw:
+        assert out["learner"]["attributes"] == dict(kw["attributes"])
+    info = capi.Booster(model_buffer=img).info()
+    assert info["num_trees"] == 5 and info["num_nodes"] == 11 and info["num_feature"] == 3
+
+
+@pytest.mark.parametrize("damage", ["garbage_trailer", "truncated_trailer", "num_deleted_lie", "flags_without_trailer"])
+def test_what_prediction_does_not_need_cannot_fail_the_load(damage, capfd):
+    """Attributes, metric names and the num_deleted counter are not needed to predict (the oracle's reader
+    never looks at them): a production file whose trailer this library mis-reads must still load."""
+    doc = _hand_doc()
+    if damage == "garbage_trailer":
+        img = helpers.legacy_image(doc, attributes=[("k", "v")], trailer=b"\xff" * 37)
+    elif damage == "truncated_trailer":
+        full = helpers.legacy_image(doc, attributes=[("k", "v")], metrics=["rmse"])
+        img = full[:-5]
+    elif damage == "num_deleted_lie":
+        img = helpers.legacy_image(doc, num_deleted_lie=3)
+    else:
+        img = helpers.legacy_image(doc, attributes=[("k", "v")], metrics=["rmse"], trailer=b"")
+    b = capi.Booster(model_buffer=img)
+    assert b.info()["num_nodes"] == 11
+    assert "[libohxgb] warning: model file:" in capfd.readouterr().err
+    cases, rows = helpers.load_hand_cases()
+    got = helpers.oracle_predict(np.frombuffer(img, dtype=np.uint8), rows, cases["missing"])
+    assert np.array_equal(got, np.float32(cases["margin"]))
+
+
+def test_poisson_files_carry_max_delta_step_between_attributes_and_metrics():
+    doc = _hand_doc()
+    img = helpers.legacy_image(doc, binf=True, objective="count:poisson", attributes=[("k", "v")],
+                               max_delta_step="0.7", metrics=["poisson-nloglik"], base_score=0.5)
+    again = synth.convert_model(np.frombuffer(img, dtype=np.uint8), "binary").tobytes()
+    assert again == img                      # every section found where it is, and written back in the same order
+
+
+def test_margins_start_from_prob_to_margin_of_the_objective():
+    """xgboost 1.6.0 keeps the user's base_score in the file and starts margins from
+    obj->ProbToMargin(base_score); a binary file from xgboost < 1.0 already holds the margin.  Identity for
+    the OH model; pinned here for the others so that option_mask = 1 is not silently off (both oracles;
+    the GPU library against them in tests/test_gpu_parity.py)."""
+    doc = _hand_doc()
+    cases, rows = helpers.load_hand_cases()
+    for t in doc["learner"]["gradient_booster"]["model"]["trees"][:2]:
+        t["split_conditions"] = [0.0]        # drop the +-1e8 stumps: keep the start value visible
+    lmp = doc["learner"]["learner_model_param"]
+    ident = O.predict(O.load_model(json.dumps(doc).encode()), rows, missing=cases["missing"])
+    for objective, base, start in (("binary:logistic", 0.25, -np.log(np.float32(3.0))),
+                                   ("count:poisson", 0.5, np.log(np.float32(0.5))),
+                                   ("reg:gamma", 2.0, np.log(np.float32(2.0)))):
+        doc["learner"]["objective"]["name"] = objective
+        lmp["base_score"] = repr(base)
+        m = O.load_model(json.dumps(doc).encode())
+        assert abs(float(m.base_score) - float(start)) < 1e-6
+        got = O.predict(m, rows, missing=cases["missing"])
+        shifted = (ident - np.float32(float(_hand_doc()["learner"]["learner_model_param"]["base_score"]))) + m.base_score
+        assert np.allclose(got, shifted, atol=1e-5)
+        # the C oracle, through a 1.6 binary image and through a pre-1.0 one (margin stored as is)
+        new = helpers.oracle_predict(np.frombuffer(helpers.legacy_image(doc, version=(1, 6)), dtype=np.uint8), rows,
+                                     cases["missing"], option_mask=1)
+        assert np.array_equal(helpers.bits(new), helpers.bits(got))
+        old = helpers.oracle_predict(np.frombuffer(helpers.legacy_image(doc, version=(0, 0)), dtype=np.uint8), rows,
+                                     cases["missing"], option_mask=1)
+        m.base_score = np.float32(base)
+        assert np.array_equal(helpers.bits(old), helpers.bits(O.predict(m, rows, missing=cases["missing"])))
