@@ -110,10 +110,11 @@ def kernel_symbol(kernel_arg, info, prefetch):
     return f"predict_rows_tile_kernel<{fmt},{chains},{'true' if prefetch else 'false'}>"
 
 
-def fortran_cpu_leg(model_image, grid, levels, threads, workdir):
-    """oracle/lib/oh_mock_driver_oracle on the first `levels` levels of the batch: the Fortran host's
+def fortran_cpu_leg(model_image, grid, fields, levels, threads, workdir):
+    """oracle/lib/oh_mock_driver_oracle on the first `levels` levels of the batch's MAPL fields: the Fortran host's
     predict_OH_with_XGB (gather + XGDMatrixCreateFromMat + XGBoosterPredict + 10**) over the oracle library.
-    Returns (gridcells per second, OH_ML[levels*plane] in row order, seconds)."""
+    `fields` = the 27 fields in HBM (torch tensors, Fortran order).  Returns (gridcells per second,
+    OH_ML[levels*plane] in row order, seconds)."""
     import struct
     import subprocess
     from quickchem_amd import synth
@@ -123,16 +124,10 @@ def fortran_cpu_leg(model_image, grid, levels, threads, workdir):
     if not os.path.exists(state):
         with open(state, "wb") as f:
             f.write(struct.pack("<iiiiff", im, jm, levels, 1, 4000.0, 1.0))
-            dev = torch.device("cuda", torch.cuda.current_device())
-            buf = torch.empty(plane * km, dtype=torch.float32, device=dev)
-            synth.field_device(grid, synth.PL_FEATURE, buf)
-            f.write(buf[:plane * levels].cpu().numpy().tobytes())                    # pl (Pa): the slab test
-            f.write(np.zeros(plane, dtype=np.float32).tobytes())                        # tropp below every level: all predicted
+            f.write(fields[synth.PL_FEATURE][:plane * levels].cpu().numpy().tobytes())     # pl (Pa): the slab test
+            f.write(np.zeros(plane, dtype=np.float32).tobytes())                            # tropp below every level: all predicted
             for feat in range(synth.NFEAT):
-                two_d = synth.IS2D[feat]
-                synth.field_device(grid, feat, buf)
-                f.write(buf[:plane if two_d else plane * levels].cpu().numpy().tobytes())
-            del buf
+                f.write(fields[feat][:plane if synth.IS2D[feat] else plane * levels].cpu().numpy().tobytes())
     model = os.path.join(workdir, "oh.model")
     if not os.path.exists(model):
         open(model, "wb").write(bytes(model_image))
@@ -154,40 +149,55 @@ def fortran_cpu_leg(model_image, grid, levels, threads, workdir):
     return n / seconds, oh, seconds
 
 
-def cpu_baseline(model_image, grid, out_dev, budget_s):
+def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
     """The reference-equivalent CPU path next to the GPU number: Fortran host + oracle, one
-    thread and all host cores, on the first levels of the same batch; its OH_ML is compared with 10**(GPU
-    margin).  A real libxgboost, if this machine has one, is timed and compared as well."""
+    thread and all host cores, on the first levels of the batch's 27 MAPL fields; its OH_ML is compared with the
+    GPU's fused call on the same fields.  A real libxgboost, if this machine has one, is timed and compared as well."""
     import shutil
     import tempfile
     from quickchem_amd import capi, synth
     im, jm, km = grid
     plane = im * jm
     cores = os.cpu_count() or 1
+    dev = out_dev.device
+    fields = []
+    for feat in range(synth.NFEAT):
+        t = torch.empty(plane * (1 if synth.IS2D[feat] else km), dtype=torch.float32, device=dev)
+        synth.field_device(grid, feat, t)
+        fields.append(t)
     workdir = tempfile.mkdtemp(prefix="ohx_cpu_leg_")
     try:
         # one level: the one-thread figure and the probe for the all-cores sample
-        r1, oh1, t1 = fortran_cpu_leg(model_image, grid, 1, 1, workdir)
-        rp, _, tp = fortran_cpu_leg(model_image, grid, 1, cores, workdir)
+        r1, oh1, t1 = fortran_cpu_leg(model_image, grid, fields, 1, 1, workdir)
+        rp, _, tp = fortran_cpu_leg(model_image, grid, fields, 1, cores, workdir)
         levels = int(max(1, min(km, 24, (0.6 * budget_s * rp) // plane)))
         if levels > 1:
-            rate, oh, secs = fortran_cpu_leg(model_image, grid, levels, cores, workdir)
+            rate, oh, secs = fortran_cpu_leg(model_image, grid, fields, levels, cores, workdir)
         else:
             rate, oh, secs = rp, oh1, tp
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
     n = plane * levels
-    # the checker's verdict on the timed GPU output: 10.0**margin as flang computes it vs float32 pow of the GPU margin
-    got = np.power(np.float32(10.0), out_dev[:n].cpu().numpy(), dtype=np.float32)
-    ulp = np.abs(got.view(np.int32).astype(np.int64) - oh.view(np.int32).astype(np.int64)).max()
+    # the checker's verdict: the same fields through the GPU's fused call (gather, PL/100, walk, 10**) vs the
+    # Fortran host + oracle; 10.0**x is libm-specific, hence 2 ulp (the raw margins are compared bit for bit below)
+    oh_gpu = torch.zeros(plane * km, dtype=torch.float32, device=dev)
+    booster.predict_fields_device([t.data_ptr() for t in fields], synth.IS2D, synth.PL_FEATURE, im, jm, km, 1, levels,
+                                  synth.XX_MISS, oh_gpu.data_ptr(), apply_pow10=True, ohscale=1.0,
+                                  stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    booster.check()
+    got = oh_gpu[:n].cpu().numpy()
+    ulp = int(np.abs(got.view(np.int32).astype(np.int64) - oh.view(np.int32).astype(np.int64)).max())
     if ulp > 2:
         raise SystemExit(f"bench: GPU OH differs from the Fortran CPU path by {ulp} ulp on the cpu_baseline sample")
+    del fields, oh_gpu
     base = {"value": rate, "unit": "gridcells/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
             "sample": f"first {levels} of {km} levels ({n} gridcells) of the batch: oracle/lib/oh_mock_driver_oracle = the "
                       f"Fortran host's predict_OH_with_XGB (SoA->AoS gather, XGDMatrixCreateFromMat, XGBoosterPredict, "
                       f"10**pred; OH_GridCompMod.F90:308-374) linked against oracle/xgb_oracle.c, OMP_NUM_THREADS={cores} "
                       f"(gather and 10** single-threaded as in the reference), {secs:.2f} s; libxgboost 1.6.0 itself is "
                       f"not available here",
+            "oh_max_ulp_vs_gpu_fused_call": ulp,
             "one_thread": {"value": r1, "unit": "gridcells/s", "cores": 1,
                            "sample": f"first level ({plane} gridcells), same executable, OMP_NUM_THREADS=1, {t1:.2f} s"},
             "libxgboost": None}
@@ -538,7 +548,7 @@ def main():
     cpu = None
     plain = (not args.shuffle and not args.missing_ppm and args.trees == 100 and args.depth == 18)
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and plain:
-        cpu = cpu_baseline(model.image, grid, out_local, args.cpu_seconds)
+        cpu = cpu_baseline(model.image, grid, booster, out_local, args.cpu_seconds)
         # and bit for bit on the raw margins, oracle through ctypes, first 2**18 rows
         lib = capi.declare_xgb_api(C.CDLL(os.path.join(ROOT, "oracle", "lib", "liboracle_xgb.so")))
         n_chk = min(n_local, 1 << 18)

@@ -211,10 +211,27 @@ typedef struct OHXRun1Args {
   float *oh_boost;                   /* export OH_boost = OH_ML*OHscale (may be NULL) */
   float *ndwet;                      /* DIAG_NDWET (may be NULL) */
   int32_t *k1, *k2;                  /* HOST pointers, 1-based slab (may be NULL) */
+  /* optional dumps of the engineered features - the reference's DIAG_* exports, its only in-model
+   * debugging hook (:1607-1640, OH_StateSpecs.rc:41-73); each may be NULL.  (im,jm,km), strato3 (im,jm):
+   * PL_BST (Pa), tauclwDN, taucliDN, taucliUP, tauclwUP, aodUP, aodDN, the layer aod, stratO3 */
+  float *diag_pl_bst, *diag_tauclwdn, *diag_tauclidn, *diag_taucliup, *diag_tauclwup;
+  float *diag_aodup, *diag_aoddn, *diag_aod, *diag_strato3;
 } OHXRun1Args;
 
 int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args);
 int OHXBoosterRun1Device(BoosterHandle handle, const OHXRun1Args* args, void* stream);
+
+/* The tail of OH Run1 alone, for a tick that does not call Boost (compute_once_per_day and nhms > 0,
+ * OH_GridCompMod.F90:1189-1193): with oh_ml = the OH_ML*OHscale kept from the last Boost,
+ *   PL_MOD, TV_MOD, NDWET_MOD as above (:1247-1257);
+ *   OH = PL_MOD > TROPP ? oh_ml : default_OH ; OH = (OH*NDWET_MOD)*1.0e-6      (:1579-1595)
+ * ndwet may be NULL.  Host form stages through HBM; device form takes device pointers and enqueues. */
+int OHXOHPostProcess(int im, int jm, int km, float avogad, float runiv, float epsilon, const float* ple_mod,
+                     const float* t_mod, const float* q_mod, const float* tropp_mod, const float* default_oh,
+                     const float* oh_ml, float* oh, float* ndwet);
+int OHXOHPostProcessDevice(int im, int jm, int km, float avogad, float runiv, float epsilon, const float* d_ple_mod,
+                           const float* d_t_mod, const float* d_q_mod, const float* d_tropp_mod,
+                           const float* d_default_oh, const float* d_oh_ml, float* d_oh, float* d_ndwet, void* stream);
 
 /* The solar geometry of OH Run1.  OHXJulianDay: JulianDay(nymd) with the reference's leap_year
  * (OH_GridCompMod.F90:1905-1970; host integer arithmetic).  OHXSolarGeometry: latarr =

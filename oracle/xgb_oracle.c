@@ -629,7 +629,32 @@ typedef struct {
   const float *default_oh;
   float *oh, *oh_boost, *ndwet;
   int32_t *k1, *k2;
+  float *diag_pl_bst, *diag_tauclwdn, *diag_tauclidn, *diag_taucliup, *diag_tauclwup;
+  float *diag_aodup, *diag_aoddn, *diag_aod, *diag_strato3;
 } OracleRun1Args;
+
+/* The tail of OH Run1 alone (the product's OHXOHPostProcess): PL_MOD, TV_MOD, NDWET_MOD (:1247-1257), the
+ * tropopause mask (:1579-1587) and the conversion to molec/cm3 (:1595), with oh_ml given. */
+ORACLE_EXPORT int OHXOHPostProcess(int im, int jm, int km, float avogad, float runiv, float epsilon,
+                                   const float* ple_mod, const float* t_mod, const float* q_mod,
+                                   const float* tropp_mod, const float* default_oh, const float* oh_ml, float* oh,
+                                   float* ndwet) {
+  if (im <= 0 || jm <= 0 || km <= 0) return fail("OHXOHPostProcess: im, jm, km must be positive");
+  if (!ple_mod || !t_mod || !q_mod || !tropp_mod || !default_oh || !oh_ml || !oh)
+    return fail("OHXOHPostProcess: a required field pointer is NULL");
+  const size_t plane = (size_t)im * (size_t)jm, vol = plane * (size_t)km;
+  for (size_t m = 0; m < vol; ++m) {
+    const size_t c = m % plane;
+    const float pl = (ple_mod[m] + ple_mod[m + plane]) * 0.5f;                  /* :1247 */
+    const float q = q_mod[m];
+    const float tv = t_mod[m] * (1.0f + q / epsilon) / (1.0f + q);             /* :1250 */
+    const float nd = (avogad * pl) / (runiv * tv);                              /* :1257 */
+    const float ohv = (pl > tropp_mod[c]) ? oh_ml[m] : default_oh[m];           /* :1579-1587 */
+    oh[m] = (ohv * nd) * 1.0e-6f;                                               /* :1595 */
+    if (ndwet) ndwet[m] = nd;
+  }
+  return 0;
+}
 
 ORACLE_EXPORT int OHXBoosterRun1(void* booster, const OracleRun1Args* a) {
   const int im = a->im, jm = a->jm, km = a->km;
@@ -677,6 +702,16 @@ ORACLE_EXPORT int OHXBoosterRun1(void* booster, const OracleRun1Args* a) {
     if (a->k2) *a->k2 = k2;
     for (size_t m = 0; m < vol; ++m) oh_ml[m] = oh_ml[m] * a->ohscale;          /* :1569 */
     if (a->oh_boost) memcpy(a->oh_boost, oh_ml, vol * sizeof(float));           /* :1571-1572 */
+    /* the DIAG_* dumps of the engineered features (:1607-1640) */
+    if (a->diag_pl_bst) memcpy(a->diag_pl_bst, pl_bst, vol * sizeof(float));
+    if (a->diag_tauclwdn) memcpy(a->diag_tauclwdn, tauclwdn, vol * sizeof(float));
+    if (a->diag_tauclidn) memcpy(a->diag_tauclidn, tauclidn, vol * sizeof(float));
+    if (a->diag_taucliup) memcpy(a->diag_taucliup, taucliup, vol * sizeof(float));
+    if (a->diag_tauclwup) memcpy(a->diag_tauclwup, tauclwup, vol * sizeof(float));
+    if (a->diag_aodup) memcpy(a->diag_aodup, aodup, vol * sizeof(float));
+    if (a->diag_aoddn) memcpy(a->diag_aoddn, aoddn, vol * sizeof(float));
+    if (a->diag_aod) memcpy(a->diag_aod, aod, vol * sizeof(float));
+    if (a->diag_strato3) memcpy(a->diag_strato3, strato3, plane * sizeof(float));
     for (size_t m = 0; m < vol; ++m) {
       const size_t c = m % plane;
       const float q = a->q_mod[m];

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "XGDMatrixSaveBinary", "XGDMatrixCreateFromFile", "XGBoosterCreate", "XGBoosterFree", "XGBoosterLoadModel",
     "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXDMatrixInferGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
-    "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device",
+    "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device", "OHXOHPostProcess", "OHXOHPostProcessDevice",
     "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXReleaseScratch",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
@@ -49,7 +49,12 @@ class OHXRun1Args(C.Structure):
                 [("scacoef", C.c_void_p * 7)] +
                 [(n, C.c_void_p) for n in ("gmito3", "gmitto3", "lat_deg", "t_bst", "no2", "o3", "ch4", "co", "isop",
                                            "acet", "c2h6", "c3h8", "prpe", "alk4", "mp", "h2o2", "cloud", "qv", "albuv",
-                                           "ch2o", "sza", "default_oh", "oh", "oh_boost", "ndwet", "k1", "k2")])
+                                           "ch2o", "sza", "default_oh", "oh", "oh_boost", "ndwet", "k1", "k2",
+                                           "diag_pl_bst", "diag_tauclwdn", "diag_tauclidn", "diag_taucliup",
+                                           "diag_tauclwup", "diag_aodup", "diag_aoddn", "diag_aod", "diag_strato3")])
+
+RUN1_DIAG_3D = ["diag_pl_bst", "diag_tauclwdn", "diag_tauclidn", "diag_taucliup", "diag_tauclwup", "diag_aodup",
+                "diag_aoddn", "diag_aod"]
 
 
 RUN1_INPUTS_3D = ["t_mod", "q_mod", "tauclw", "taucli", "t_bst", "no2", "o3", "ch4", "co", "isop", "acet", "c2h6", "c3h8",
@@ -104,6 +109,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                                                   i32, i32, f32, i32, f32, vp, vp, vp]
     lib.OHXBoosterRun1.argtypes = [vp, C.POINTER(OHXRun1Args)]
     lib.OHXBoosterRun1Device.argtypes = [vp, C.POINTER(OHXRun1Args), vp]
+    lib.OHXOHPostProcess.argtypes = [i32, i32, i32, f32, f32, f32] + [vp] * 8
+    lib.OHXOHPostProcessDevice.argtypes = [i32, i32, i32, f32, f32, f32] + [vp] * 9
     lib.OHXJulianDay.argtypes = [i32, C.POINTER(i32)]
     lib.OHXSolarGeometry.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp]
     lib.OHXSolarGeometryDevice.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp, vp]
@@ -289,7 +296,8 @@ class Booster:
 
     def run1(self, state: dict, *, dynamic_k_range: bool, tropp_min: float = 4000.0, ohscale: float = 0.85,
              missing: float = -999.0, avogad: float = 6.023e26, runiv: float = 8314.47,
-             epsilon: float = 18.015 / 28.965, want_boost: bool = True, want_ndwet: bool = True) -> dict:
+             epsilon: float = 18.015 / 28.965, want_boost: bool = True, want_ndwet: bool = True,
+             want_diag: bool = False) -> dict:
         """OHXBoosterRun1 on host arrays.  `state` maps the names of OHXRun1Args to [i,j(,k)]-indexed
         float32 arrays (edge fields have km+1 levels; "scacoef" is a list of seven).  Returns
         {"oh", "oh_boost", "ndwet", "k1", "k2"} with arrays indexed [i,j,k]."""
@@ -317,9 +325,19 @@ class Booster:
         args.ndwet = ndwet.ctypes.data if want_ndwet else None
         args.k1 = C.cast(C.pointer(k1), C.c_void_p)
         args.k2 = C.cast(C.pointer(k2), C.c_void_p)
+        diag = {}
+        if want_diag:
+            for name in RUN1_DIAG_3D:
+                diag[name] = np.zeros(im * jm * km, dtype=np.float32)
+                setattr(args, name, diag[name].ctypes.data)
+            diag["diag_strato3"] = np.zeros(im * jm, dtype=np.float32)
+            args.diag_strato3 = diag["diag_strato3"].ctypes.data
         check(self.lib, self.lib.OHXBoosterRun1(self.handle, C.byref(args)))
         unflat = lambda a: None if a is None else a.reshape(km, jm, im).transpose(2, 1, 0)   # noqa: E731
-        return {"oh": unflat(oh), "oh_boost": unflat(boost), "ndwet": unflat(ndwet), "k1": k1.value, "k2": k2.value}
+        out = {"oh": unflat(oh), "oh_boost": unflat(boost), "ndwet": unflat(ndwet), "k1": k1.value, "k2": k2.value}
+        for name, a in diag.items():
+            out[name] = a.reshape(jm, im).T if name == "diag_strato3" else unflat(a)
+        return out
 
     def info(self) -> dict:
         arr = (C.c_uint64 * 8)()
@@ -338,6 +356,21 @@ class Booster:
             self.free()
         except Exception:
             pass
+
+
+def oh_post_process(ple_mod, t_mod, q_mod, tropp_mod, default_oh, oh_ml, *, avogad: float = 6.023e26,
+                    runiv: float = 8314.47, epsilon: float = 18.015 / 28.965, lib: Optional[C.CDLL] = None):
+    """OHXOHPostProcess on [i,j(,k)]-indexed float32 arrays -> (oh, ndwet), indexed [i,j,k]."""
+    lib = lib or load_library()
+    if not hasattr(lib.OHXOHPostProcess, "argtypes") or lib.OHXOHPostProcess.argtypes is None:
+        lib.OHXOHPostProcess.argtypes = [C.c_int] * 3 + [C.c_float] * 3 + [C.c_void_p] * 8
+    flat = [np.ascontiguousarray(np.asarray(a, dtype=np.float32).T) for a in (ple_mod, t_mod, q_mod, tropp_mod, default_oh, oh_ml)]
+    im, jm, km = np.asarray(t_mod).shape
+    oh = np.zeros(im * jm * km, dtype=np.float32)
+    ndwet = np.zeros(im * jm * km, dtype=np.float32)
+    check(lib, lib.OHXOHPostProcess(im, jm, km, avogad, runiv, epsilon, *[a.ctypes.data for a in flat], oh.ctypes.data,
+                                    ndwet.ctypes.data))
+    return oh.reshape(km, jm, im).transpose(2, 1, 0), ndwet.reshape(km, jm, im).transpose(2, 1, 0)
 
 
 def device_count() -> int:

@@ -629,11 +629,7 @@ int XGDMatrixFree(DMatrixHandle handle) {
   API_END();
 }
 
-int OHXReleaseScratch(void) {
-  API_BEGIN();
-  g_row_pool.release_all();
-  API_END();
-}
+int OHXReleaseScratch(void);   // defined at the end of the file: it knows every pool
 
 int XGDMatrixNumRow(DMatrixHandle handle, bst_ulong* out) {
   API_BEGIN();
@@ -1015,10 +1011,14 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   b.d_run1[8].ensure(vol);
   b.d_run1[9].ensure(vol);
   b.d_slab.ensure(2);
-  float* pl_bst = b.d_run1[0].p;
-  float *tauclwdn = b.d_run1[1].p, *tauclidn = b.d_run1[2].p, *taucliup = b.d_run1[3].p, *tauclwup = b.d_run1[4].p;
-  float *aodup = b.d_run1[5].p, *aoddn = b.d_run1[6].p, *strato3 = b.d_run1[7].p;
-  float* oh_ml = r.oh_boost ? r.oh_boost : b.d_run1[8].p;
+  // a DIAG buffer the caller gave IS the place the feature is built in; scratch otherwise
+  auto or_scratch = [&](float* wanted, int slot) { return wanted ? wanted : b.d_run1[slot].p; };
+  float* pl_bst = or_scratch(r.diag_pl_bst, 0);
+  float *tauclwdn = or_scratch(r.diag_tauclwdn, 1), *tauclidn = or_scratch(r.diag_tauclidn, 2);
+  float *taucliup = or_scratch(r.diag_taucliup, 3), *tauclwup = or_scratch(r.diag_tauclwup, 4);
+  float *aodup = or_scratch(r.diag_aodup, 5), *aoddn = or_scratch(r.diag_aoddn, 6), *strato3 = or_scratch(r.diag_strato3, 7);
+  float* oh_ml = or_scratch(r.oh_boost, 8);
+  float* aod = or_scratch(r.diag_aod, 9);
 
   PrepArgs pa;
   pa.im = r.im; pa.jm = r.jm; pa.km = r.km;
@@ -1027,7 +1027,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   pa.gmito3 = r.gmito3; pa.gmitto3 = r.gmitto3;
   pa.pl_bst = pl_bst; pa.tauclwdn = tauclwdn; pa.tauclidn = tauclidn; pa.taucliup = taucliup; pa.tauclwup = tauclwup;
   pa.aodup = aodup; pa.aoddn = aoddn; pa.strato3 = strato3;
-  HIP_CHECK(launch_feature_prep(pa, b.d_run1[9].p, stream));
+  HIP_CHECK(launch_feature_prep(pa, aod, stream));
 
   SlabArgs sa;
   sa.im = r.im; sa.jm = r.jm; sa.km = r.km;
@@ -1085,6 +1085,68 @@ int OHXBoosterRun1Device(BoosterHandle handle, const OHXRun1Args* args, void* st
     throw OhxError("objective '" + b->forest.objective + "' is not supported by OHXBoosterRun1");
   ensure_uploaded(*b);
   run1_device(*b, *args, static_cast<hipStream_t>(stream));
+  API_END();
+}
+
+static PostArgs post_args(int im, int jm, int km, float avogad, float runiv, float epsilon, const float* ple_mod,
+                          const float* t_mod, const float* q_mod, const float* tropp_mod, const float* default_oh,
+                          const float* oh_ml, float* oh, float* ndwet) {
+  if (im <= 0 || jm <= 0 || km <= 0) throw OhxError("OHXOHPostProcess: im, jm, km must be positive");
+  if (!ple_mod || !t_mod || !q_mod || !tropp_mod || !default_oh || !oh_ml || !oh)
+    throw OhxError("OHXOHPostProcess: a required field pointer is NULL");
+  PostArgs po;
+  po.im = im; po.jm = jm; po.km = km;
+  po.avogad = avogad; po.runiv = runiv; po.epsilon = epsilon;
+  po.ple_mod = ple_mod; po.t_mod = t_mod; po.q_mod = q_mod; po.tropp = tropp_mod;
+  po.default_oh = default_oh; po.oh_ml = oh_ml; po.oh = oh; po.ndwet = ndwet;
+  return po;
+}
+
+int OHXOHPostProcessDevice(int im, int jm, int km, float avogad, float runiv, float epsilon, const float* d_ple_mod,
+                           const float* d_t_mod, const float* d_q_mod, const float* d_tropp_mod,
+                           const float* d_default_oh, const float* d_oh_ml, float* d_oh, float* d_ndwet, void* stream) {
+  API_BEGIN();
+  (void)use_device(-1);
+  HIP_CHECK(launch_post_process(post_args(im, jm, km, avogad, runiv, epsilon, d_ple_mod, d_t_mod, d_q_mod, d_tropp_mod,
+                                          d_default_oh, d_oh_ml, d_oh, d_ndwet), static_cast<hipStream_t>(stream)));
+  API_END();
+}
+
+namespace {
+// staging of the host form: one set of device buffers per process, reused from tick to tick
+struct PostScratch {
+  std::mutex mu;
+  int device = -1;
+  DevBuf<float> buf[8];
+};
+PostScratch g_post;
+}  // namespace
+
+int OHXOHPostProcess(int im, int jm, int km, float avogad, float runiv, float epsilon, const float* ple_mod,
+                     const float* t_mod, const float* q_mod, const float* tropp_mod, const float* default_oh,
+                     const float* oh_ml, float* oh, float* ndwet) {
+  API_BEGIN();
+  (void)post_args(im, jm, km, avogad, runiv, epsilon, ple_mod, t_mod, q_mod, tropp_mod, default_oh, oh_ml, oh, ndwet);
+  const DeviceInfo dev = use_device(-1);
+  const size_t plane = (size_t)im * (size_t)jm, vol = plane * (size_t)km, edge = plane * (size_t)(km + 1);
+  std::lock_guard<std::mutex> g(g_post.mu);
+  if (g_post.device != dev.ordinal) {
+    for (auto& bf : g_post.buf) bf.release();
+    g_post.device = dev.ordinal;
+  }
+  const float* src[6] = {ple_mod, t_mod, q_mod, tropp_mod, default_oh, oh_ml};
+  const size_t n[6] = {edge, vol, vol, plane, vol, vol};
+  for (int i = 0; i < 6; ++i) {
+    g_post.buf[i].ensure(n[i]);
+    HIP_CHECK(hipMemcpyAsync(g_post.buf[i].p, src[i], n[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
+  }
+  g_post.buf[6].ensure(vol);
+  if (ndwet) g_post.buf[7].ensure(vol);
+  HIP_CHECK(launch_post_process(post_args(im, jm, km, avogad, runiv, epsilon, g_post.buf[0].p, g_post.buf[1].p,
+                                          g_post.buf[2].p, g_post.buf[3].p, g_post.buf[4].p, g_post.buf[5].p,
+                                          g_post.buf[6].p, ndwet ? g_post.buf[7].p : nullptr), nullptr));
+  HIP_CHECK(hipMemcpy(oh, g_post.buf[6].p, vol * sizeof(float), hipMemcpyDeviceToHost));
+  if (ndwet) HIP_CHECK(hipMemcpy(ndwet, g_post.buf[7].p, vol * sizeof(float), hipMemcpyDeviceToHost));
   API_END();
 }
 
@@ -1172,7 +1234,7 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
       {h.cloud, &d.cloud, vol}, {h.qv, &d.qv, vol}, {h.albuv, &d.albuv, plane}, {h.ch2o, &d.ch2o, vol},
       {h.sza, &d.sza, plane}, {h.default_oh, &d.default_oh, vol}};
   const size_t nin = sizeof(ins) / sizeof(ins[0]);
-  if (b->d_run1_stage.size() < nin + 3) b->d_run1_stage.resize(nin + 3);
+  if (b->d_run1_stage.size() < nin + 3 + 9) b->d_run1_stage.resize(nin + 3 + 9);
   for (size_t i = 0; i < nin; ++i) {
     if (ins[i].host == nullptr) throw OhxError("OHXBoosterRun1: a required field pointer is NULL");
     b->d_run1_stage[i].ensure(ins[i].n);
@@ -1192,10 +1254,26 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
     b->d_run1_stage[nin + 2].ensure(vol);
     d.oh_boost = b->d_run1_stage[nin + 2].p;
   }
+  // DIAG dumps: device copies only for the ones asked for
+  struct Out { float* host; float** dev; size_t n; };
+  Out outs[] = {{h.diag_pl_bst, &d.diag_pl_bst, vol}, {h.diag_tauclwdn, &d.diag_tauclwdn, vol},
+                {h.diag_tauclidn, &d.diag_tauclidn, vol}, {h.diag_taucliup, &d.diag_taucliup, vol},
+                {h.diag_tauclwup, &d.diag_tauclwup, vol}, {h.diag_aodup, &d.diag_aodup, vol},
+                {h.diag_aoddn, &d.diag_aoddn, vol}, {h.diag_aod, &d.diag_aod, vol}, {h.diag_strato3, &d.diag_strato3, plane}};
+  const size_t nout = sizeof(outs) / sizeof(outs[0]);
+  if (b->d_run1_stage.size() < nin + 3 + nout) b->d_run1_stage.resize(nin + 3 + nout);
+  for (size_t i = 0; i < nout; ++i) {
+    *outs[i].dev = nullptr;
+    if (outs[i].host == nullptr) continue;
+    b->d_run1_stage[nin + 3 + i].ensure(outs[i].n);
+    *outs[i].dev = b->d_run1_stage[nin + 3 + i].p;
+  }
   run1_device(*b, d, nullptr);
   HIP_CHECK(hipMemcpy(h.oh, d.oh, vol * sizeof(float), hipMemcpyDeviceToHost));
   if (h.ndwet) HIP_CHECK(hipMemcpy(h.ndwet, d.ndwet, vol * sizeof(float), hipMemcpyDeviceToHost));
   if (h.oh_boost) HIP_CHECK(hipMemcpy(h.oh_boost, d.oh_boost, vol * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < nout; ++i)
+    if (outs[i].host) HIP_CHECK(hipMemcpy(outs[i].host, *outs[i].dev, outs[i].n * sizeof(float), hipMemcpyDeviceToHost));
   raise_flag_errors(*b, nullptr);
   API_END();
 }
@@ -1236,6 +1314,16 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
   info[5] = b->forest.num_feature;
   info[6] = super_used ? 2 : (packed_used ? 1 : 0);
   info[7] = super_used ? super_gathers : 0;
+  API_END();
+}
+
+int OHXReleaseScratch(void) {
+  API_BEGIN();
+  g_row_pool.release_all();
+  {
+    std::lock_guard<std::mutex> g(g_post.mu);
+    for (auto& bf : g_post.buf) bf.release();
+  }
   API_END();
 }
 

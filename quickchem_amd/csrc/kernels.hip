@@ -250,9 +250,9 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
 #pragma unroll
   for (int c = 0; c < CHAINS; ++c) {
     asm volatile("" : "+v"(s[c]));   // one 128-bit tuple: see "pin_super" above
-    // meta & 0x1F00 is the byte offset of the node's feature row; a leaf (feature 31) reads a
-    // row that belongs to nobody (past the allocation an LDS read returns zero) and the
-    // value is not used
+    // meta & 0x1F00 is the byte offset of the node's feature row; a leaf (feature 31) reads row 31, which
+    // is the next wave's tile or the first-step table (tile_lds_bytes keeps it inside the block's
+    // allocation) and the value is not used
     x0[c] = *reinterpret_cast<const float*>(tile_b + (s[c].w & 0x1F00u));
   }
 #pragma unroll
@@ -402,8 +402,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  char* first = reinterpret_cast<char*>(lds);
-  float* tile = lds + (FMT == 2 ? kFirstBytes / 4 : 0) + (size_t)wave * fr.num_feature * kWave + lane;
+  // the waves' feature tiles first, the first-step table behind them (see tile_lds_bytes)
+  float* tile = lds + (size_t)wave * fr.num_feature * kWave + lane;
+  char* first = reinterpret_cast<char*>(lds + (size_t)kWavesPerBlock * fr.num_feature * kWave);
   const uint32_t nfirst = fill_first_steps<FMT>(fr, heads, first);
   const bool missing_is_nan = a.missing != a.missing;
   // Blocks b and b + 8 share an XCD (round-robin dispatch, observed, speed only): give
@@ -495,8 +496,8 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  char* first = reinterpret_cast<char*>(lds);
-  float* tile = lds + (FMT == 2 ? kFirstBytes / 4 : 0) + (size_t)wave * fr.num_feature * kWave + lane;
+  float* tile = lds + (size_t)wave * fr.num_feature * kWave + lane;
+  char* first = reinterpret_cast<char*>(lds + (size_t)kWavesPerBlock * fr.num_feature * kWave);
   const uint32_t nfirst = fill_first_steps<FMT>(fr, heads, first);
   const bool missing_is_nan = a.missing != a.missing;
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
@@ -715,12 +716,17 @@ int grid_for(uint64_t work_items, int num_cus, int blocks_per_cu) {
   return (int)blocks;
 }
 
-// Feature tiles of the block's waves.  The super-node walk reads "row 31" for a leaf and
-// ignores the value; for the last wave of a block that address lies past the allocation, where
-// an LDS read returns zero (the hardware range-checks LDS addresses; no fault).  Padding the
-// allocation instead costs a whole block of occupancy per CU (5 x 28 928 B no longer fits).
+// LDS of a block: the feature tiles of its waves, then (super-nodes) the first-step table.  The super-node
+// walk reads "feature row 31" for a leaf and ignores the value; that row must be memory the block owns.
+// Row 31 of a wave's tile lies in the next wave's tile, and for the last wave in the first-step table, as
+// long as the allocation reaches (3 * num_feature + 32) rows - which tiles + table already do for the OH
+// booster (27 features: 31 744 B against 28 928 B, so five blocks still share a CU); boosters with few
+// features get the padding.
 size_t tile_lds_bytes(uint32_t num_feature, bool super_format) {
-  return (size_t)kWavesPerBlock * num_feature * kWave * sizeof(float) + (super_format ? kFirstBytes : 0);
+  const size_t tiles = (size_t)kWavesPerBlock * num_feature * kWave * sizeof(float);
+  if (!super_format) return tiles;
+  const size_t reach = ((size_t)(kWavesPerBlock - 1) * num_feature + 32) * kWave * sizeof(float);
+  return tiles + kFirstBytes > reach ? tiles + kFirstBytes : reach;
 }
 
 template <class K>

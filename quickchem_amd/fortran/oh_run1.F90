@@ -11,7 +11,8 @@ module oh_run1
    implicit none
    private
 
-   public :: OH_RUN1_STATE, oh_run1_boost, oh_solar_geometry, oh_julian_day, oh_run1_error_text
+   public :: OH_RUN1_STATE, OH_RUN1_DIAG, oh_run1_boost, oh_post_process, oh_solar_geometry, oh_julian_day
+   public :: oh_run1_error_text
 
    !  struct OHXRun1Args, member for member
    type, bind(C) :: OHXRun1Args
@@ -28,6 +29,8 @@ module oh_run1
       type(c_ptr) :: default_oh
       type(c_ptr) :: oh, oh_boost, ndwet
       type(c_ptr) :: k1, k2
+      type(c_ptr) :: diag_pl_bst, diag_tauclwdn, diag_tauclidn, diag_taucliup, diag_tauclwup
+      type(c_ptr) :: diag_aodup, diag_aoddn, diag_aod, diag_strato3
    end type
 
    !  What Run1 has in hand when it reaches CALL_BOOST (:1557), by the reference's names.
@@ -48,7 +51,22 @@ module oh_run1
       real, pointer, dimension(:,:,:) :: default_OH => null()
    end type
 
+   !  The engineered features, for the DIAG_* exports of :1607-1640: associate the ones that are wanted
+   type OH_RUN1_DIAG
+      real, pointer, dimension(:,:,:) :: PL_BST => null(), tauclwDN => null(), taucliDN => null(), taucliUP => null(), &
+                                         tauclwUP => null(), aodUP => null(), aodDN => null(), aod => null()
+      real, pointer, dimension(:,:)   :: stratO3 => null()
+   end type
+
    interface
+      function OHXOHPostProcess(im, jm, km, avogad, runiv, epsilon, ple_mod, t_mod, q_mod, tropp_mod, default_oh, &
+                                oh_ml, oh, ndwet) bind(C, name="OHXOHPostProcess") result(rc)
+         import :: c_int, c_float, c_ptr
+         integer(c_int), value :: im, jm, km
+         real(c_float), value  :: avogad, runiv, epsilon
+         type(c_ptr), value    :: ple_mod, t_mod, q_mod, tropp_mod, default_oh, oh_ml, oh, ndwet
+         integer(c_int)        :: rc
+      end function
       function OHXBoosterRun1(handle, args) bind(C, name="OHXBoosterRun1") result(rc)
          import :: c_ptr, c_int, OHXRun1Args
          type(c_ptr), value            :: handle
@@ -105,22 +123,53 @@ contains
       end if
    end subroutine
 
-   type(c_ptr) function loc3(a)
+   !  Address of a field for the C side, or NULL with an error text: the library reads n1*n2*n3 floats from
+   !  it, so a strided section or an array of another shape must never get through (ADVICE r1).
+   type(c_ptr) function loc3(a, n1, n2, n3, name)
       real, pointer, intent(in) :: a(:,:,:)
+      integer, intent(in) :: n1, n2, n3
+      character(len=*), intent(in) :: name
       loc3 = c_null_ptr
-      if (associated(a)) loc3 = c_loc(a(lbound(a,1), lbound(a,2), lbound(a,3)))
+      if (.not. associated(a)) then
+         if (len_trim(last_error) == 0) last_error = 'oh_run1: field '//name//' is not associated'
+         return
+      end if
+      if (.not. is_contiguous(a) .or. size(a,1) /= n1 .or. size(a,2) /= n2 .or. size(a,3) /= n3) then
+         if (len_trim(last_error) == 0) last_error = 'oh_run1: field '//name//' is not a contiguous array of the expected shape'
+         return
+      end if
+      loc3 = c_loc(a(lbound(a,1), lbound(a,2), lbound(a,3)))
    end function
 
-   type(c_ptr) function loc2(a)
+   type(c_ptr) function loc2(a, n1, n2, name)
       real, pointer, intent(in) :: a(:,:)
+      integer, intent(in) :: n1, n2
+      character(len=*), intent(in) :: name
       loc2 = c_null_ptr
-      if (associated(a)) loc2 = c_loc(a(lbound(a,1), lbound(a,2)))
+      if (.not. associated(a)) then
+         if (len_trim(last_error) == 0) last_error = 'oh_run1: field '//name//' is not associated'
+         return
+      end if
+      if (.not. is_contiguous(a) .or. size(a,1) /= n1 .or. size(a,2) /= n2) then
+         if (len_trim(last_error) == 0) last_error = 'oh_run1: field '//name//' is not a contiguous array of the expected shape'
+         return
+      end if
+      loc2 = c_loc(a(lbound(a,1), lbound(a,2)))
+   end function
+
+   !  optional outputs: NULL when not wanted, checked like the inputs when they are
+   type(c_ptr) function opt3(a, n1, n2, n3, name)
+      real, pointer, intent(in) :: a(:,:,:)
+      integer, intent(in) :: n1, n2, n3
+      character(len=*), intent(in) :: name
+      opt3 = c_null_ptr
+      if (associated(a)) opt3 = loc3(a, n1, n2, n3, name)
    end function
 
    !  CALL_BOOST and what surrounds it (:1444-1478, 1488, 1557-1595) in one call.
    !  OH is the INTERNAL field (molec/cm3), OH_boost the export OH_ML*OHscale, NDWET the diagnostic.
    subroutine oh_run1_boost(XGBoostFilename, im, jm, km, dynamic_k_range, tropp_min, OHscale, &
-                            avogad, runiv, epsilon, st, OH, OH_boost, NDWET, k1, k2, rc)
+                            avogad, runiv, epsilon, st, OH, OH_boost, NDWET, k1, k2, rc, diag)
       character(len=*), intent(in) :: XGBoostFilename
       integer, intent(in)  :: im, jm, km
       logical, intent(in)  :: dynamic_k_range
@@ -128,6 +177,7 @@ contains
       type(OH_RUN1_STATE), intent(in) :: st
       real, intent(out), target, contiguous :: OH(:,:,:), OH_boost(:,:,:), NDWET(:,:,:)
       integer, intent(out) :: k1, k2, rc
+      type(OH_RUN1_DIAG), intent(in), optional :: diag
       type(OHXRun1Args) :: a
       type(c_ptr) :: bst
       integer(c_int32_t), target :: ck1, ck2
@@ -140,23 +190,54 @@ contains
          last_error = 'oh_run1_boost: the booster could not be loaded'
          return
       end if
+      if (any(shape(OH) /= [im, jm, km]) .or. any(shape(OH_boost) /= [im, jm, km]) .or. any(shape(NDWET) /= [im, jm, km])) then
+         last_error = 'oh_run1_boost: OH, OH_boost and NDWET must be (im,jm,km)'
+         rc = OH_XGB_FAILURE
+         return
+      end if
+      last_error = ''
       a%im = im; a%jm = jm; a%km = km
       a%dynamic_k_range = merge(1, 0, dynamic_k_range)
       a%tropp_min = tropp_min; a%ohscale = OHscale; a%missing = -999.0     ! :213
       a%avogad = avogad; a%runiv = runiv; a%epsilon = epsilon
-      a%ple_mod = loc3(st%PLE_MOD); a%t_mod = loc3(st%T_MOD); a%q_mod = loc3(st%Q_MOD); a%tropp_mod = loc2(st%TROPP_MOD)
-      a%ple_bst = loc3(st%PLE_BST); a%zle_bst = loc3(st%ZLE_BST); a%tauclw = loc3(st%TAUCLW); a%taucli = loc3(st%TAUCLI)
-      a%scacoef(1) = loc3(st%BCscacoef); a%scacoef(2) = loc3(st%OCscacoef); a%scacoef(3) = loc3(st%BRscacoef)
-      a%scacoef(4) = loc3(st%DUscacoef); a%scacoef(5) = loc3(st%SUscacoef); a%scacoef(6) = loc3(st%SSscacoef)
-      a%scacoef(7) = loc3(st%NIscacoef)
-      a%gmito3 = loc2(st%GMITO3); a%gmitto3 = loc2(st%GMITTO3); a%lat_deg = loc2(st%latarr)
-      a%t_bst = loc3(st%T_BST); a%no2 = loc3(st%NO2); a%o3 = loc3(st%O3); a%ch4 = loc3(st%CH4); a%co = loc3(st%CO)
-      a%isop = loc3(st%ISOP); a%acet = loc3(st%ACET); a%c2h6 = loc3(st%C2H6); a%c3h8 = loc3(st%C3H8)
-      a%prpe = loc3(st%PRPE); a%alk4 = loc3(st%ALK4); a%mp = loc3(st%MP); a%h2o2 = loc3(st%H2O2)
-      a%cloud = loc3(st%CLOUD); a%qv = loc3(st%QV); a%albuv = loc2(st%ALBUV); a%ch2o = loc3(st%CH2O)
-      a%sza = loc2(st%sza_noon); a%default_oh = loc3(st%default_OH)
+      a%ple_mod = loc3(st%PLE_MOD, im, jm, km + 1, 'PLE_MOD'); a%t_mod = loc3(st%T_MOD, im, jm, km, 'T_MOD')
+      a%q_mod = loc3(st%Q_MOD, im, jm, km, 'Q_MOD'); a%tropp_mod = loc2(st%TROPP_MOD, im, jm, 'TROPP_MOD')
+      a%ple_bst = loc3(st%PLE_BST, im, jm, km + 1, 'PLE_BST'); a%zle_bst = loc3(st%ZLE_BST, im, jm, km + 1, 'ZLE_BST')
+      a%tauclw = loc3(st%TAUCLW, im, jm, km, 'TAUCLW'); a%taucli = loc3(st%TAUCLI, im, jm, km, 'TAUCLI')
+      a%scacoef(1) = loc3(st%BCscacoef, im, jm, km, 'BCscacoef'); a%scacoef(2) = loc3(st%OCscacoef, im, jm, km, 'OCscacoef')
+      a%scacoef(3) = loc3(st%BRscacoef, im, jm, km, 'BRscacoef'); a%scacoef(4) = loc3(st%DUscacoef, im, jm, km, 'DUscacoef')
+      a%scacoef(5) = loc3(st%SUscacoef, im, jm, km, 'SUscacoef'); a%scacoef(6) = loc3(st%SSscacoef, im, jm, km, 'SSscacoef')
+      a%scacoef(7) = loc3(st%NIscacoef, im, jm, km, 'NIscacoef')
+      a%gmito3 = loc2(st%GMITO3, im, jm, 'GMITO3'); a%gmitto3 = loc2(st%GMITTO3, im, jm, 'GMITTO3')
+      a%lat_deg = loc2(st%latarr, im, jm, 'latarr')
+      a%t_bst = loc3(st%T_BST, im, jm, km, 'T_BST'); a%no2 = loc3(st%NO2, im, jm, km, 'NO2'); a%o3 = loc3(st%O3, im, jm, km, 'O3')
+      a%ch4 = loc3(st%CH4, im, jm, km, 'CH4'); a%co = loc3(st%CO, im, jm, km, 'CO'); a%isop = loc3(st%ISOP, im, jm, km, 'ISOP')
+      a%acet = loc3(st%ACET, im, jm, km, 'ACET'); a%c2h6 = loc3(st%C2H6, im, jm, km, 'C2H6')
+      a%c3h8 = loc3(st%C3H8, im, jm, km, 'C3H8'); a%prpe = loc3(st%PRPE, im, jm, km, 'PRPE')
+      a%alk4 = loc3(st%ALK4, im, jm, km, 'ALK4'); a%mp = loc3(st%MP, im, jm, km, 'MP'); a%h2o2 = loc3(st%H2O2, im, jm, km, 'H2O2')
+      a%cloud = loc3(st%CLOUD, im, jm, km, 'CLOUD'); a%qv = loc3(st%QV, im, jm, km, 'QV')
+      a%albuv = loc2(st%ALBUV, im, jm, 'ALBUV'); a%ch2o = loc3(st%CH2O, im, jm, km, 'CH2O')
+      a%sza = loc2(st%sza_noon, im, jm, 'sza_noon'); a%default_oh = loc3(st%default_OH, im, jm, km, 'default_OH')
+      if (len_trim(last_error) /= 0) then
+         rc = OH_XGB_FAILURE
+         return
+      end if
       a%oh = c_loc(OH(1,1,1)); a%oh_boost = c_loc(OH_boost(1,1,1)); a%ndwet = c_loc(NDWET(1,1,1))
       a%k1 = c_loc(ck1); a%k2 = c_loc(ck2)
+      a%diag_pl_bst = c_null_ptr; a%diag_tauclwdn = c_null_ptr; a%diag_tauclidn = c_null_ptr
+      a%diag_taucliup = c_null_ptr; a%diag_tauclwup = c_null_ptr; a%diag_aodup = c_null_ptr
+      a%diag_aoddn = c_null_ptr; a%diag_aod = c_null_ptr; a%diag_strato3 = c_null_ptr
+      if (present(diag)) then
+         a%diag_pl_bst = opt3(diag%PL_BST, im, jm, km, 'diag PL_BST'); a%diag_tauclwdn = opt3(diag%tauclwDN, im, jm, km, 'diag tauclwDN')
+         a%diag_tauclidn = opt3(diag%taucliDN, im, jm, km, 'diag taucliDN'); a%diag_taucliup = opt3(diag%taucliUP, im, jm, km, 'diag taucliUP')
+         a%diag_tauclwup = opt3(diag%tauclwUP, im, jm, km, 'diag tauclwUP'); a%diag_aodup = opt3(diag%aodUP, im, jm, km, 'diag aodUP')
+         a%diag_aoddn = opt3(diag%aodDN, im, jm, km, 'diag aodDN'); a%diag_aod = opt3(diag%aod, im, jm, km, 'diag aod')
+         if (associated(diag%stratO3)) a%diag_strato3 = loc2(diag%stratO3, im, jm, 'diag stratO3')
+         if (len_trim(last_error) /= 0) then
+            rc = OH_XGB_FAILURE
+            return
+         end if
+      end if
       crc = OHXBoosterRun1(bst, a)
       if (crc /= 0) then
          last_error = 'Failed in OHXBoosterRun1 :: '//ohx_last_error()
@@ -165,6 +246,38 @@ contains
       end if
       k1 = ck1
       k2 = ck2
+   end subroutine
+
+   !  The tropopause mask and the unit conversion alone (:1247-1257, 1579-1595), for a tick that does not call
+   !  Boost (compute_once_per_day, :1189-1193): OH_ML is the persisted self%OH_ML, already scaled.
+   subroutine oh_post_process(im, jm, km, avogad, runiv, epsilon, PLE_MOD, T_MOD, Q_MOD, TROPP_MOD, default_OH, OH_ML, &
+                              OH, NDWET, rc)
+      integer, intent(in) :: im, jm, km
+      real, intent(in)    :: avogad, runiv, epsilon
+      real, pointer, intent(in) :: PLE_MOD(:,:,:), T_MOD(:,:,:), Q_MOD(:,:,:), TROPP_MOD(:,:), default_OH(:,:,:)
+      real, intent(in), target, contiguous  :: OH_ML(:,:,:)
+      real, intent(out), target, contiguous :: OH(:,:,:), NDWET(:,:,:)
+      integer, intent(out) :: rc
+      type(c_ptr) :: p_ple, p_t, p_q, p_tropp, p_def
+      integer(c_int) :: crc
+      rc = OH_XGB_SUCCESS
+      last_error = ''
+      p_ple = loc3(PLE_MOD, im, jm, km + 1, 'PLE_MOD'); p_t = loc3(T_MOD, im, jm, km, 'T_MOD')
+      p_q = loc3(Q_MOD, im, jm, km, 'Q_MOD'); p_tropp = loc2(TROPP_MOD, im, jm, 'TROPP_MOD')
+      p_def = loc3(default_OH, im, jm, km, 'default_OH')
+      if (len_trim(last_error) == 0 .and. (any(shape(OH_ML) /= [im, jm, km]) .or. any(shape(OH) /= [im, jm, km]) .or. &
+                                           any(shape(NDWET) /= [im, jm, km]))) &
+         last_error = 'oh_post_process: OH_ML, OH and NDWET must be (im,jm,km)'
+      if (len_trim(last_error) /= 0) then
+         rc = OH_XGB_FAILURE
+         return
+      end if
+      crc = OHXOHPostProcess(int(im, c_int), int(jm, c_int), int(km, c_int), avogad, runiv, epsilon, p_ple, p_t, p_q, &
+                             p_tropp, p_def, c_loc(OH_ML(1,1,1)), c_loc(OH(1,1,1)), c_loc(NDWET(1,1,1)))
+      if (crc /= 0) then
+         last_error = 'Failed in OHXOHPostProcess :: '//ohx_last_error()
+         rc = OH_XGB_FAILURE
+      end if
    end subroutine
 
 end module oh_run1

@@ -355,30 +355,32 @@ contains
       rc = OH_XGB_SUCCESS
    end subroutine predict_OH_with_XGB
 
-   !  C address of a field; the fused kernel reads the arrays in place, so they
-   !  must be contiguous (MAPL pointers are).
-   function addr3(a, ok) result(p)
+   !  C address of a field; the fused kernel reads n1*n2(*n3) floats in place, so the array must be
+   !  contiguous (MAPL pointers are) and of exactly that shape.
+   function addr3(a, n1, n2, n3, ok) result(p)
       real, pointer, intent(in) :: a(:,:,:)
+      integer, intent(in) :: n1, n2, n3
       logical, intent(inout) :: ok
       type(c_ptr) :: p
       p = c_null_ptr
       if (.not. associated(a)) then
          ok = .false.
-      else if (.not. is_contiguous(a)) then
+      else if (.not. is_contiguous(a) .or. size(a,1) /= n1 .or. size(a,2) /= n2 .or. size(a,3) /= n3) then
          ok = .false.
       else
          p = c_loc(a(lbound(a,1), lbound(a,2), lbound(a,3)))
       end if
    end function
 
-   function addr2(a, ok) result(p)
+   function addr2(a, n1, n2, ok) result(p)
       real, pointer, intent(in) :: a(:,:)
+      integer, intent(in) :: n1, n2
       logical, intent(inout) :: ok
       type(c_ptr) :: p
       p = c_null_ptr
       if (.not. associated(a)) then
          ok = .false.
-      else if (.not. is_contiguous(a)) then
+      else if (.not. is_contiguous(a) .or. size(a,1) /= n1 .or. size(a,2) /= n2) then
          ok = .false.
       else
          p = c_loc(a(lbound(a,1), lbound(a,2)))
@@ -413,37 +415,37 @@ contains
       call oh_xgb_k_slab(icount, jcount, kcount, dynamic_k_range, tropp_min, pl, tropp, k1, k2, rc)
       if (rc /= OH_XGB_SUCCESS) return
 
-      ok = .true.
+      ok = all(shape(OH_ML) == [icount, jcount, kcount])
       is2d(:) = 0
-      fields( 1) = addr2(bb%LAT, ok);        is2d( 1) = 1
-      fields( 2) = addr3(bb%PL, ok)
-      fields( 3) = addr3(bb%T, ok)
-      fields( 4) = addr3(bb%NO2, ok)
-      fields( 5) = addr3(bb%O3, ok)
-      fields( 6) = addr3(bb%CH4, ok)
-      fields( 7) = addr3(bb%CO, ok)
-      fields( 8) = addr3(bb%ISOP, ok)
-      fields( 9) = addr3(bb%ACET, ok)
-      fields(10) = addr3(bb%C2H6, ok)
-      fields(11) = addr3(bb%C3H8, ok)
-      fields(12) = addr3(bb%PRPE, ok)
-      fields(13) = addr3(bb%ALK4, ok)
-      fields(14) = addr3(bb%MP, ok)
-      fields(15) = addr3(bb%H2O2, ok)
-      fields(16) = addr3(bb%TAUCLWDN, ok)
-      fields(17) = addr3(bb%TAUCLIDN, ok)
-      fields(18) = addr3(bb%TAUCLIUP, ok)
-      fields(19) = addr3(bb%TAUCLWUP, ok)
-      fields(20) = addr3(bb%CLOUD, ok)
-      fields(21) = addr3(bb%QV, ok)
-      fields(22) = addr2(bb%GMISTRATO3, ok); is2d(22) = 1
-      fields(23) = addr2(bb%ALBUV, ok);      is2d(23) = 1
-      fields(24) = addr3(bb%AODUP, ok)
-      fields(25) = addr3(bb%AODDN, ok)
-      fields(26) = addr3(bb%CH2O, ok)
-      fields(27) = addr2(bb%SZA, ok);        is2d(27) = 1
+      fields( 1) = addr2(bb%LAT, icount, jcount, ok);        is2d( 1) = 1
+      fields( 2) = addr3(bb%PL, icount, jcount, kcount, ok)
+      fields( 3) = addr3(bb%T, icount, jcount, kcount, ok)
+      fields( 4) = addr3(bb%NO2, icount, jcount, kcount, ok)
+      fields( 5) = addr3(bb%O3, icount, jcount, kcount, ok)
+      fields( 6) = addr3(bb%CH4, icount, jcount, kcount, ok)
+      fields( 7) = addr3(bb%CO, icount, jcount, kcount, ok)
+      fields( 8) = addr3(bb%ISOP, icount, jcount, kcount, ok)
+      fields( 9) = addr3(bb%ACET, icount, jcount, kcount, ok)
+      fields(10) = addr3(bb%C2H6, icount, jcount, kcount, ok)
+      fields(11) = addr3(bb%C3H8, icount, jcount, kcount, ok)
+      fields(12) = addr3(bb%PRPE, icount, jcount, kcount, ok)
+      fields(13) = addr3(bb%ALK4, icount, jcount, kcount, ok)
+      fields(14) = addr3(bb%MP, icount, jcount, kcount, ok)
+      fields(15) = addr3(bb%H2O2, icount, jcount, kcount, ok)
+      fields(16) = addr3(bb%TAUCLWDN, icount, jcount, kcount, ok)
+      fields(17) = addr3(bb%TAUCLIDN, icount, jcount, kcount, ok)
+      fields(18) = addr3(bb%TAUCLIUP, icount, jcount, kcount, ok)
+      fields(19) = addr3(bb%TAUCLWUP, icount, jcount, kcount, ok)
+      fields(20) = addr3(bb%CLOUD, icount, jcount, kcount, ok)
+      fields(21) = addr3(bb%QV, icount, jcount, kcount, ok)
+      fields(22) = addr2(bb%GMISTRATO3, icount, jcount, ok); is2d(22) = 1
+      fields(23) = addr2(bb%ALBUV, icount, jcount, ok);      is2d(23) = 1
+      fields(24) = addr3(bb%AODUP, icount, jcount, kcount, ok)
+      fields(25) = addr3(bb%AODDN, icount, jcount, kcount, ok)
+      fields(26) = addr3(bb%CH2O, icount, jcount, kcount, ok)
+      fields(27) = addr2(bb%SZA, icount, jcount, ok);        is2d(27) = 1
       if (.not. ok) then
-         last_error = 'predict_OH_with_XGB_fused: every bb field must be associated and contiguous'
+         last_error = 'predict_OH_with_XGB_fused: every bb field must be associated, contiguous and (icount,jcount[,kcount])'
          rc = OH_XGB_FAILURE
          return
       end if

@@ -200,3 +200,73 @@ def test_run1_fortran_host_on_the_gpu(tmp_path, small_model):
     b = capi.Booster(model_buffer=small_model.image)
     py = b.run1(st, dynamic_k_range=True)
     assert np.array_equal(helpers.bits(oh), helpers.bits(py["oh"])) and (k1, k2) == (py["k1"], py["k2"])
+
+
+def test_post_process_and_diag_dumps_of_the_oracle():
+    """OHXOHPostProcess (the tail of Run1 on a tick that skips Boost) and the DIAG_* dumps, oracle against plain
+    numpy float32 expressions in the reference's order (:1247-1257, 1444-1478, 1579-1595)."""
+    grid = (5, 4, 18)
+    st = helpers.run1_state(grid, seed=8)
+    f32 = np.float32
+    oh_ml = (st["default_oh"] * f32(3.0)).astype(f32)
+    eps = float(f32(18.015) / f32(28.965))
+    oh, ndwet = capi.oh_post_process(st["ple_mod"], st["t_mod"], st["q_mod"], st["tropp_mod"], st["default_oh"], oh_ml,
+                                     epsilon=eps, lib=helpers.oracle_lib())
+    pl = ((st["ple_mod"][:, :, :-1] + st["ple_mod"][:, :, 1:]) * f32(0.5)).astype(f32)
+    tv = (st["t_mod"] * (f32(1.0) + st["q_mod"] / f32(eps)) / (f32(1.0) + st["q_mod"])).astype(f32)
+    nd = ((f32(6.023e26) * pl) / (f32(8314.47) * tv)).astype(f32)
+    pick = np.where(pl > st["tropp_mod"][:, :, None], oh_ml, st["default_oh"]).astype(f32)
+    assert np.array_equal(helpers.bits(ndwet), helpers.bits(nd))
+    assert np.array_equal(helpers.bits(oh), helpers.bits(((pick * nd).astype(f32) * f32(1e-6)).astype(f32)))
+
+
+def test_diag_dumps_of_the_oracle(small_model):
+    grid = (5, 4, 18)
+    st = helpers.run1_state(grid, seed=8)
+    f32 = np.float32
+    out = oracle_run1(small_model.image, st, dynamic_k_range=True, want_diag=True)
+    km = grid[2]
+    thick = (st["zle_bst"][:, :, :-1] - st["zle_bst"][:, :, 1:]).astype(f32)
+    sc = st["scacoef"][0] + st["scacoef"][1]
+    for a in st["scacoef"][2:]:
+        sc = (sc + a).astype(f32)
+    aod = (thick * sc).astype(f32)
+    assert np.array_equal(helpers.bits(out["diag_aod"]), helpers.bits(aod))
+    up = np.zeros(grid, f32)
+    run = np.zeros(grid[:2], f32)
+    for k in range(km):
+        run = (run + st["tauclw"][:, :, k]).astype(f32)
+        up[:, :, k] = run
+    assert np.array_equal(helpers.bits(out["diag_tauclwup"]), helpers.bits(up))
+    dn = np.zeros(grid, f32)
+    for k in range(km):
+        s = np.zeros(grid[:2], f32)
+        for kk in range(k, km):
+            s = (s + aod[:, :, kk]).astype(f32)
+        dn[:, :, k] = s
+    assert np.array_equal(helpers.bits(out["diag_aoddn"]), helpers.bits(dn))
+    assert np.array_equal(out["diag_strato3"], (st["gmito3"] - st["gmitto3"]).astype(f32))
+    assert np.array_equal(out["diag_pl_bst"], ((st["ple_bst"][:, :, :-1] + st["ple_bst"][:, :, 1:]) * f32(0.5)).astype(f32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [(4, 4, 72), (37, 11, 40)])
+def test_post_process_and_diag_dumps_on_the_gpu(small_model, grid):
+    """The same two on the MI355X against the oracle: every dump and the post-processed OH bit for bit."""
+    st = helpers.run1_state(grid, seed=grid[1])
+    eps = float(np.float32(18.015) / np.float32(28.965))
+    want = oracle_run1(small_model.image, st, dynamic_k_range=True, epsilon=eps, want_diag=True)
+    b = capi.Booster(model_buffer=small_model.image)
+    got = b.run1(st, dynamic_k_range=True, epsilon=eps, want_diag=True)
+    for name in capi.RUN1_DIAG_3D + ["diag_strato3", "ndwet"]:
+        assert np.array_equal(helpers.bits(got[name]), helpers.bits(want[name])), name
+    # asking for the dumps changes nothing else
+    plain = b.run1(st, dynamic_k_range=True, epsilon=eps)
+    assert np.array_equal(helpers.bits(plain["oh"]), helpers.bits(got["oh"]))
+    oh_ml = want["oh_boost"]
+    a = capi.oh_post_process(st["ple_mod"], st["t_mod"], st["q_mod"], st["tropp_mod"], st["default_oh"], oh_ml, epsilon=eps)
+    c = capi.oh_post_process(st["ple_mod"], st["t_mod"], st["q_mod"], st["tropp_mod"], st["default_oh"], oh_ml, epsilon=eps,
+                             lib=helpers.oracle_lib())
+    assert np.array_equal(helpers.bits(a[0]), helpers.bits(c[0])) and np.array_equal(helpers.bits(a[1]), helpers.bits(c[1]))
+    with pytest.raises(capi.OhxError, match="NULL"):
+        capi.check(b.lib, b.lib.OHXOHPostProcess(4, 4, 4, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None))
