@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--gather-chunks", type=int, default=4,
                     help="N > 1: cut the shard into this many pieces so that a piece's all-gather overlaps the next "
                          "piece's prediction (1 = predict everything, then one all-gather)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "native"],
+                    help="N > 1: the all-gather through torch.distributed (RCCL process group), or through the C ABI's "
+                         "own OHXAllGatherOH (what a Fortran/MPI host would call)")
     ap.add_argument("--path", default="rows", choices=["rows", "fields", "run1"],
                     help="rows: AoS xx_carr -> margins (the headline); fields: the fused SoA call, 27 MAPL fields -> "
                          "10**pred*OHscale; run1: OHXBoosterRun1Device, imports -> INTERNAL OH (both 1 GPU only)")
@@ -473,20 +476,30 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    chunks = shard.ChunkGather(out_full, n_local, world, pieces) if (gather and len(pieces) > 1) else None
+    native = None
+    if gather and args.gather == "native":
+        # the C-ABI route a Fortran/MPI host would take (include/ohxgb.h part 4): RCCL through libohxgb.so itself;
+        # the 128-byte id travels over torch.distributed here, over MPI_Bcast there
+        ids = [capi.Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        native = capi.Communicator(ids[0], world, rank)
+
     def step(i=None):
         if i is not None:
             ev0[i].record(stream)
-        works = []
-        for (lo, hi), dm in zip(pieces, dmats):
+        for q, ((lo, hi), dm) in enumerate(zip(pieces, dmats)):
             booster.predict_device(dm, out_local.data_ptr() + lo * 4, stream=stream.cuda_stream)
-            if gather and len(pieces) > 1:
-                works.append(shard.all_gather_chunk_async(out_full, out_local, lo, hi, n_local, world))
+            if chunks is not None and native is None:
+                chunks.start(q, out_local)
         if i is not None:
             ev1[i].record(stream)      # with N > 1 this spans the predict launches of all pieces
-        if gather and len(pieces) == 1:
+        if native is not None:
+            native.all_gather_oh(out_local.data_ptr(), n_local, n_total, out_full.data_ptr(), stream=stream.cuda_stream)
+        elif chunks is not None:
+            chunks.finish()
+        elif gather:
             shard.all_gather_rows(out_full, out_local, n_total, world, even)
-        for w in works:
-            w.wait()
 
     def fence():
         torch.cuda.synchronize()
@@ -581,6 +594,7 @@ def main():
                           "build_s": round(t_model, 2)},
                 "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid), "grid_known_to_library": list(dmats[0].grid()), "verified": verified,
                 "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
+                "gather_via": (args.gather if gather else None),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -253,6 +253,28 @@ int OHXSolarGeometryDevice(int jday, const float* d_lats, const float* d_lons, i
  * [7] gather instructions one wavefront issues to walk the whole forest once (super-nodes). */
 int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]);
 
+/* ------------------------------------------------------------------------
+ * Part 4 — reassembling the OH field across the GPUs of a node (additive)
+ * ------------------------------------------------------------------------
+ * Inside GEOS nothing is exchanged: every rank keeps the block it predicted
+ * (OH_GridCompMod.F90:1199-1202, 1565).  For a caller that wants the whole field on every GPU
+ * (BASELINE.json configs #4/#5) the gridcell rows are cut into contiguous shards, rank r of N holding
+ * OHXShardRows' rows, and ONE collective - an RCCL all-gather over xGMI - puts every shard at its rows of
+ * d_full on every rank.  Set-up as RCCL's own: rank 0 calls OHXCommGetUniqueId, the host distributes the
+ * OHX_UNIQUE_ID_BYTES bytes by whatever it has (MPI_Bcast in a GEOS-like host), every rank - its HIP device
+ * already current - calls OHXCommInitRank.  OHXAllGatherOH only enqueues on `stream`; d_shard may be
+ * d_full + row0 (in place).  Equal shards are one ncclAllGather; ragged ones one group of broadcasts.
+ * librccl.so is loaded at the first of these calls, not linked. */
+typedef void* OHXCommHandle;
+#define OHX_UNIQUE_ID_BYTES 128
+int OHXCommGetUniqueId(void* id);
+int OHXCommInitRank(const void* id, int nranks, int rank, OHXCommHandle* out);
+int OHXCommFree(OHXCommHandle comm);
+/* rows [*row0, *row0 + *nrows) of rank `rank`: contiguous, sizes differing by at most one row */
+int OHXShardRows(bst_ulong nrows_total, int nranks, int rank, bst_ulong* row0, bst_ulong* nrows);
+int OHXAllGatherOH(OHXCommHandle comm, const float* d_shard, bst_ulong nrows_local, bst_ulong nrows_total,
+                   float* d_full, void* stream);
+
 /* Returns the device buffers the library keeps between calls to the driver: freed DMatrix storage parked
  * for the next XGDMatrixCreateFromMat (the reference creates and frees its matrix on every OH tick,
  * OH_GridCompMod.F90:347,377; at most two buffers are kept; OHX_DMATRIX_POOL=0 in the environment keeps

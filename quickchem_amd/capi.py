@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXDMatrixInferGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device", "OHXOHPostProcess", "OHXOHPostProcessDevice",
     "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXReleaseScratch",
+    "OHXCommGetUniqueId", "OHXCommInitRank", "OHXCommFree", "OHXShardRows", "OHXAllGatherOH",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
 REFERENCE_BOUND_SYMBOLS = [
@@ -116,6 +117,11 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.OHXSolarGeometryDevice.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp, vp]
     lib.OHXBoosterGetInfo.argtypes = [vp, C.POINTER(u64)]
     lib.OHXReleaseScratch.argtypes = []
+    lib.OHXCommGetUniqueId.argtypes = [vp]
+    lib.OHXCommInitRank.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    lib.OHXCommFree.argtypes = [vp]
+    lib.OHXShardRows.argtypes = [u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
+    lib.OHXAllGatherOH.argtypes = [vp, vp, u64, u64, vp, vp]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -371,6 +377,50 @@ def oh_post_process(ple_mod, t_mod, q_mod, tropp_mod, default_oh, oh_ml, *, avog
     check(lib, lib.OHXOHPostProcess(im, jm, km, avogad, runiv, epsilon, *[a.ctypes.data for a in flat], oh.ctypes.data,
                                     ndwet.ctypes.data))
     return oh.reshape(km, jm, im).transpose(2, 1, 0), ndwet.reshape(km, jm, im).transpose(2, 1, 0)
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def shard_rows(n_total: int, nranks: int, rank: int, lib: Optional[C.CDLL] = None):
+    """OHXShardRows -> (row0, nrows)."""
+    lib = lib or load_library()
+    r0, n = C.c_uint64(), C.c_uint64()
+    check(lib, lib.OHXShardRows(n_total, nranks, rank, C.byref(r0), C.byref(n)))
+    return r0.value, n.value
+
+
+class Communicator:
+    """OHXCommInitRank handle: the RCCL communicator a Fortran/MPI host would build through the C ABI.
+    `unique_id` = the 128 bytes rank 0 got from Communicator.unique_id(), distributed by the caller."""
+
+    def __init__(self, unique_id: bytes, nranks: int, rank: int, lib: Optional[C.CDLL] = None):
+        self.lib = lib or load_library()
+        self.handle = C.c_void_p()
+        self.nranks, self.rank = nranks, rank
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        check(self.lib, self.lib.OHXCommInitRank(C.cast(buf, C.c_void_p), nranks, rank, C.byref(self.handle)))
+
+    @staticmethod
+    def unique_id(lib: Optional[C.CDLL] = None) -> bytes:
+        lib = lib or load_library()
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        check(lib, lib.OHXCommGetUniqueId(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def all_gather_oh(self, shard_ptr: int, n_local: int, n_total: int, full_ptr: int, stream: int = 0) -> None:
+        check(self.lib, self.lib.OHXAllGatherOH(self.handle, shard_ptr, n_local, n_total, full_ptr, stream or None))
+
+    def free(self) -> None:
+        if self.handle:
+            check(self.lib, self.lib.OHXCommFree(self.handle))
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def device_count() -> int:

@@ -33,6 +33,14 @@ thread_local std::string g_last_error;
 
 void set_error(const std::string& m) { g_last_error = m; }
 
+}  // namespace
+
+namespace ohx {
+void set_last_error(const std::string& m) { g_last_error = m; }   // for comm.cpp
+}
+
+namespace {
+
 #define API_BEGIN() try {
 #define API_END()                                   \
   }                                                 \
@@ -242,6 +250,8 @@ struct DMatrixObj {
   uint64_t grid_row0 = 0;
   bool grid_inferred = false;     // found by infer_level_size, not said by the caller
   bool grid_looked = false;       // the rows have been searched (or the caller has spoken): do not look again
+  // rows in no known order: has the clustering pass been judged worth it for this matrix, and was it?
+  bool cluster_decided = false, cluster_on = false;
 };
 
 struct BoosterObj {
@@ -279,6 +289,9 @@ struct BoosterObj {
   // Run1: engineered features, OH_ML and the slab result stay in HBM between the steps
   DevBuf<float> d_run1[10];
   DevBuf<int32_t> d_slab;
+  // clustering pass for rows in no known order (cluster.hip)
+  DevBuf<uint32_t> d_cluster_keys, d_cluster_perm, d_cluster_counters, d_cluster_small;
+  PinnedBuf<uint32_t> h_cluster_small;
   std::vector<DevBuf<float>> d_run1_stage;
 };
 
@@ -492,6 +505,52 @@ void infer_level_size(DMatrixObj& d, hipStream_t stream) {
   adopt_level_size(d, g_check.h.p, kmax);
 }
 
+// Rows nobody has described and in which no level size was found: group them by the decisions they take at
+// the top of the booster's first trees (cluster.hip) and let every wave take 64 rows of one group.  Returns the
+// permutation to walk through, or nullptr for "as they come".  Judged once per matrix (one wait on the stream,
+// like the level-size search): rows that mostly agree with their predecessor are in some useful order already.
+const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a, bool pred_leaf, KernelKind kind,
+                             hipStream_t stream) {
+  constexpr uint64_t kMinRows = 1u << 18;
+  if (b.tune.cluster == 0 || pred_leaf || d.grid_im != 0 || !b.super_ok || kind == KernelKind::Wide) return nullptr;
+  if (d.nrow > 0xFFFFFFF0ull || d.ncol > b.forest.num_feature || b.forest.num_feature > 32) return nullptr;
+  if (b.tune.cluster < 0 && (d.nrow < kMinRows || (d.cluster_decided && !d.cluster_on))) return nullptr;
+  ClusterArgs c;
+  c.rows = d.d_data;
+  c.nrow = d.nrow;
+  c.ncol = (uint32_t)d.ncol;
+  c.missing = d.missing;
+  c.ntrees = (uint32_t)std::min<size_t>((size_t)std::max(b.tune.cluster_trees, 1), b.forest.trees.size());
+  c.nsteps = (uint32_t)std::max(b.tune.cluster_steps, 1);
+  while (cluster_key_bits(c) > 24u && c.nsteps > 1) --c.nsteps;
+  while (cluster_key_bits(c) > 24u && c.ntrees > 1) --c.ntrees;
+  const size_t ncounters = std::max<size_t>((size_t)1 << cluster_key_bits(c), 4096);
+  b.d_cluster_keys.ensure(d.nrow);
+  b.d_cluster_perm.ensure(d.nrow);
+  b.d_cluster_counters.ensure(ncounters);
+  b.d_cluster_small.ensure(4096 + 1);
+  b.h_cluster_small.ensure(1);
+  c.keys = b.d_cluster_keys.p;
+  c.perm = b.d_cluster_perm.p;
+  c.counters = b.d_cluster_counters.p;
+  c.agree = b.d_cluster_small.p + 4096;
+  HIP_CHECK(hipMemsetAsync(c.counters, 0, ncounters * sizeof(uint32_t), stream));
+  HIP_CHECK(hipMemsetAsync(c.agree, 0, sizeof(uint32_t), stream));
+  HIP_CHECK(launch_cluster_keys(device_forest(b), c, b.dev.num_cus, stream));
+  if (b.tune.cluster < 0 && !d.cluster_decided) {
+    HIP_CHECK(hipMemcpyAsync(b.h_cluster_small.p, c.agree, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    d.cluster_decided = true;
+    d.cluster_on = (double)b.h_cluster_small.p[0] < 0.5 * (double)d.nrow;
+    if (getenv("OHX_DEBUG"))
+      fprintf(stderr, "[libohxgb] cluster verdict: %u of %llu rows agree with their predecessor on the first tree's key -> %s\n",
+              b.h_cluster_small.p[0], (unsigned long long)d.nrow, d.cluster_on ? "cluster" : "leave");
+    if (!d.cluster_on) return nullptr;
+  }
+  HIP_CHECK(launch_cluster_sort(c, b.d_cluster_small.p, b.dev.num_cus, stream));
+  return c.perm;
+}
+
 void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsigned ntree_limit, float* d_out,
                             hipStream_t stream) {
   bool pred_leaf = false;
@@ -518,6 +577,7 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
   tune.grid_im = d.grid_im;
   tune.grid_jm = d.grid_jm;
   tune.grid_row0 = d.grid_row0;
+  a.perm = cluster_rows(b, d, a, pred_leaf, kind, stream);
   HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, tune));
 }
 
@@ -814,6 +874,18 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     }
   } else if (n == "ohx_brick_k_fastest") {
     b->tune.brick_k_fastest = atoi(value) != 0;
+  } else if (n == "ohx_cluster") {
+    // rows in no known order: "auto" groups them by tree-top decisions unless they look ordered; "on" / "off"
+    if (v == "auto") b->tune.cluster = -1;
+    else if (v == "on" || v == "1") b->tune.cluster = 1;
+    else if (v == "off" || v == "0") b->tune.cluster = 0;
+    else throw OhxError("ohx_cluster must be auto, on or off");
+  } else if (n == "ohx_cluster_trees") {
+    b->tune.cluster_trees = std::max(1, atoi(value));
+  } else if (n == "ohx_cluster_steps") {
+    b->tune.cluster_steps = std::max(1, atoi(value));
+  } else if (n == "ohx_tree_sync") {
+    b->tune.tree_sync = atoi(value) > 0 ? atoi(value) : 0;
   } else if (n == "ohx_lds_pad") {
     b->tune.lds_pad = atoi(value);
   } else if (n == "ohx_prefetch") {

@@ -32,6 +32,10 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// a pointer that is KNOWN to point into LDS: loads through it are ds_read, never flat_load (a generic pointer
+// into LDS whose origin the compiler loses track of goes through the texture addresser like a global load)
+typedef const __attribute__((address_space(3))) char* lds_cptr;
+typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
 
 // The packed 8-byte nodes are read through a buffer descriptor: one 64-bit load per node that the
 // compiler cannot split into dword loads (it does split a plain uint2 load when only one half
@@ -79,6 +83,16 @@ __device__ __forceinline__ uint64_t tile_row(const TileShape& sh, uint64_t tile_
   const uint64_t m = (uint64_t)i + (uint64_t)sh.im * ((uint64_t)j + (uint64_t)sh.jm * (uint64_t)k);
   *valid = i < sh.im && j < sh.jm && m >= sh.row0 && m - sh.row0 < sh.nrow;
   return m - sh.row0;
+}
+
+// the same for a launch: rows grouped by the clustering pass come through the permutation
+__device__ __forceinline__ uint64_t launch_row(const PredictArgs& a, uint64_t tile_id, int lane, bool* valid) {
+  if (a.perm != nullptr) {
+    const uint64_t slot = tile_id * kWave + lane;
+    *valid = slot < a.nrow;
+    return *valid ? (uint64_t)a.perm[slot] : 0;
+  }
+  return tile_row(a.shape, tile_id, lane, a.nrow, valid);
 }
 
 // ------------------------------------------------------------------ tile fill
@@ -290,15 +304,23 @@ constexpr uint32_t kFirstBytes = kFirstTrees * 2 * 16;
 template <int CHAINS, bool HAS_MISSING>
 __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const SuperTreeHead* __restrict__ heads,
                                             uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile,
-                                            const char* __restrict__ first, uint32_t nfirst) {
+                                            const char* __restrict__ first, uint32_t nfirst, uint32_t sync_every) {
   if (t0 >= t1) return acc;
+  const lds_cptr first_lds = (lds_cptr)first;
   const u32x4* __restrict__ nodes_v = reinterpret_cast<const u32x4*>(nodes);
   const char* tile_b = reinterpret_cast<const char*>(tile);
   // tree heads are wave-uniform (scalar loads); the next group's are fetched a whole walk ahead
   SuperTreeHead hn[CHAINS];
 #pragma unroll
   for (int c = 0; c < CHAINS; ++c) hn[c] = heads[(t0 + c < t1) ? t0 + c : t1 - 1];
+  uint32_t until_sync = sync_every;
   for (uint32_t t = t0; t < t1; t += CHAINS) {
+    // experiment knob (ohx_tree_sync): the waves of a block meet every `sync_every` groups of trees, so that
+    // four neighbouring bricks ask the L1 for the same tree's lines at the same time
+    if (sync_every != 0u && --until_sync == 0u) {
+      __builtin_amdgcn_s_barrier();
+      until_sync = sync_every;
+    }
     SuperTreeHead h[CHAINS];
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) {
@@ -332,7 +354,7 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 #pragma unroll
       for (int c = 0; c < CHAINS; ++c) {
         const uint32_t tt = (t + c < t1) ? t + c : t1 - 1;
-        s[c] = *reinterpret_cast<const u32x4*>(first + ((2u * tt + (rel[c] - 4u)) << 4));
+        s[c] = *(lds_u32x4_ptr)(first_lds + ((2u * tt + (rel[c] - 4u)) << 4));
       }
     } else {
 #pragma unroll
@@ -355,7 +377,7 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 template <int FMT, int CHAINS>
 __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads, uint32_t t0,
                                            uint32_t t1, const float* tile, bool wave_has_missing, const char* first,
-                                           uint32_t nfirst) {
+                                           uint32_t nfirst, uint32_t sync_every = 0u) {
   float acc = fr.base_score;
   if constexpr (FMT == 1) {
     const __amdgpu_buffer_rsrc_t nodes = make_rsrc(fr.packed, fr.packed_bytes);
@@ -364,8 +386,8 @@ __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTr
   } else if constexpr (FMT == 2) {
     // plain 128-bit global loads: measured 8 % faster than buffer loads on the divergent deep levels
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.super);
-    return wave_has_missing ? walk_super<CHAINS, true>(nodes, heads, t0, t1, acc, tile, first, nfirst)
-                            : walk_super<CHAINS, false>(nodes, heads, t0, t1, acc, tile, first, nfirst);
+    return wave_has_missing ? walk_super<CHAINS, true>(nodes, heads, t0, t1, acc, tile, first, nfirst, sync_every)
+                            : walk_super<CHAINS, false>(nodes, heads, t0, t1, acc, tile, first, nfirst, sync_every);
   } else {
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
     return wave_has_missing ? walk_wide_tile<true>(nodes, fr.roots, t0, t1, acc, tile)
@@ -414,13 +436,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const uint64_t wave_id = (uint64_t)block * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  // barriers need every wave of the block to make the same number of walks: whole rounds of the grid only
+  const uint32_t sync_every = (a.sync_every > 0 && (a.tile_end - a.tile_begin) % nwaves == 0) ? (uint32_t)a.sync_every : 0u;
   if constexpr (PREFETCH27) {
     uint64_t tile_id = a.tile_begin + wave_id;
     Row27 regs;
     bool valid = false;
     uint64_t row = 0;
     if (tile_id < a.tile_end) {
-      row = tile_row(a.shape, tile_id, lane, a.nrow, &valid);
+      row = launch_row(a, tile_id, lane, &valid);
       load_row27(regs, a.rows, valid ? row : 0);
     }
     while (tile_id < a.tile_end) {
@@ -429,11 +453,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
       const uint64_t this_row = row;
       const bool this_valid = valid;
       if (next < a.tile_end) {
-        row = tile_row(a.shape, next, lane, a.nrow, &valid);
+        row = launch_row(a, next, lane, &valid);
         load_row27(regs, a.rows, valid ? row : 0);   // in flight during the walk
       }
       const bool wave_nan = __any(lane_nan);
-      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
+      // (a block whose waves disagree about missing values would meet at different barriers: no sync then)
+      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst,
+                                               a.has_missing_hint ? 0u : sync_every);
       if (this_valid) __builtin_nontemporal_store(acc, out + this_row);
       tile_id = next;
     }
@@ -441,7 +467,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   }
   for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
     bool valid;
-    const uint64_t row = tile_row(a.shape, tile_id, lane, a.nrow, &valid);
+    const uint64_t row = launch_row(a, tile_id, lane, &valid);
     const bool lane_nan = fill_tile_rows(tile, a.rows, row, valid, a.ncol, fr.num_feature, a.missing,
                                          missing_is_nan, a.flags);
     const bool wave_nan = __any(lane_nan);
@@ -757,7 +783,7 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
   hipError_t e = ensure_lds(kernel, lds);
   if (e != hipSuccess) return e;
   // bricks when the caller named the grid the rows come from
-  if (tune.grid_im > 0 && tune.grid_jm > 0 && a.nrow > 0 &&
+  if (a.perm == nullptr && tune.grid_im > 0 && tune.grid_jm > 0 && a.nrow > 0 &&
       (tune.brick_li < 0 || tune.brick_li + tune.brick_lj + tune.brick_lk == 6)) {
     if (tune.brick_li < 0) a.shape.set_grid_auto((uint32_t)tune.grid_im, (uint32_t)tune.grid_jm, tune.grid_row0, a.nrow);
     else a.shape.set_grid((uint32_t)tune.grid_im, (uint32_t)tune.grid_jm, tune.grid_row0, a.nrow, (uint32_t)tune.brick_li,
@@ -768,6 +794,7 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
   const uint64_t ntiles = a.shape.ntiles(a.nrow);
   const int grid = tile_grid(kernel, lds, ntiles, num_cus);
   a.xcd_remap = tune.xcd_remap;
+  a.sync_every = tune.tree_sync;
   if (tune.launches_per_residency <= 0) {
     a.tile_begin = 0;
     a.tile_end = ntiles;

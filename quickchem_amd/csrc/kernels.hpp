@@ -91,6 +91,9 @@ struct PredictArgs {
   uint64_t tile_begin = 0;      // first 64-row tile of this launch (tile kernels)
   uint64_t tile_end = 0;        // one past the last tile of this launch
   int xcd_remap = 1;            // give each XCD a contiguous range of tiles
+  const uint32_t* perm = nullptr;  // rows grouped by cluster.hip: lane l of tile t takes row perm[64 t + l]
+  int sync_every = 0;           // experiment: waves of a block meet at a barrier every this many tree groups
+  int has_missing_hint = 0;     // (set by the launcher when the batch may hold missing values: no barriers)
   TileShape shape;              // lanes -> rows
 };
 
@@ -102,6 +105,10 @@ struct LaunchTuning {
   int xcd_remap = 1;
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
+  int tree_sync = 0;  // experiment knob: block-level barrier every this many tree groups (0 = never)
+  // rows in no known order: -1 = decide per matrix (cluster unless the rows look ordered), 0 = never, 1 = always
+  int cluster = -1;
+  int cluster_trees = 3, cluster_steps = 3;
   // rows API: the grid the rows were gathered from and the grid row the matrix starts at
   // (XGBoosterSetParam "ohx_grid" = "im,jm[,row0]").  0 = unknown, tiles are 64 consecutive rows.
   int grid_im = 0, grid_jm = 0;
@@ -169,6 +176,23 @@ hipError_t launch_solar_geometry(const SolarArgs& a, hipStream_t stream);
 hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_t stream);  // aod_scratch: (im,jm,km)
 hipError_t launch_k_slab(const SlabArgs& a, hipStream_t stream);
 hipError_t launch_post_process(const PostArgs& a, hipStream_t stream);
+
+// The clustering pass in front of the walk for rows in no known order (cluster.hip).  Device pointers.
+struct ClusterArgs {
+  const float* rows = nullptr;
+  uint64_t nrow = 0;
+  uint32_t ncol = 0;
+  float missing = 0.0f;
+  uint32_t ntrees = 3, nsteps = 3;   // key = top of the first `ntrees` trees, `nsteps` super-node steps each (<= 24 bits)
+  uint32_t* keys = nullptr;          // [nrow]
+  uint32_t* counters = nullptr;      // [max(2**bits, 4096)], zero before launch_cluster_keys; cursors afterwards
+  uint32_t* perm = nullptr;          // [nrow] row numbers grouped by key
+  uint32_t* agree = nullptr;         // one word, zero before: rows whose first-tree key equals the previous row's
+};
+uint32_t cluster_key_bits(const ClusterArgs& a);
+hipError_t launch_cluster_keys(const DeviceForest& forest, const ClusterArgs& a, int num_cus, hipStream_t stream);
+// d_block_sums: [4096] scratch words
+hipError_t launch_cluster_sort(const ClusterArgs& a, uint32_t* d_block_sums, int num_cus, hipStream_t stream);
 
 enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super3, Super4, Super5, Super6 };
 

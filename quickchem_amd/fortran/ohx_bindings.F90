@@ -15,7 +15,10 @@ module ohx_bindings
    public :: XGDMatrixCreateFromMat, XGDMatrixFree, XGDMatrixNumRow, XGDMatrixNumCol
    public :: XGBoosterCreate, XGBoosterFree, XGBoosterLoadModel, XGBoosterSaveModel
    public :: XGBoosterPredict, XGBoosterSetParam, OHXBoosterPredictFields, OHXDMatrixSetGrid
+   public :: OHXCommGetUniqueId, OHXCommInitRank, OHXCommFree, OHXShardRows, OHXAllGatherOH, OHX_UNIQUE_ID_BYTES
    public :: ohx_last_error, ohx_c_string
+
+   integer, parameter :: OHX_UNIQUE_ID_BYTES = 128
 
    interface
       ! ---- symbols bound by the reference (Shared/xgb_fortran_api.F90:19-119) ----
@@ -123,6 +126,45 @@ module ohx_bindings
          type(c_ptr), value        :: handle
          integer(c_int), value     :: im, jm
          integer(c_int64_t), value :: row0
+         integer(c_int)            :: rc
+      end function
+
+      ! ---- part 4 of ohxgb.h: the OH field reassembled on every GPU of a node, for a host that has MPI but no
+      !      torch.distributed.  Rank 0 gets the id, MPI_Bcast carries its OHX_UNIQUE_ID_BYTES bytes, every rank
+      !      (hipSetDevice done) inits; d_shard / d_full are DEVICE addresses, stream a hipStream_t (c_null_ptr = default)
+      function OHXCommGetUniqueId(id) bind(C, name="OHXCommGetUniqueId") result(rc)
+         import :: c_int, c_char
+         character(kind=c_char), intent(out) :: id(*)
+         integer(c_int)                      :: rc
+      end function
+
+      function OHXCommInitRank(id, nranks, rank, comm) bind(C, name="OHXCommInitRank") result(rc)
+         import :: c_int, c_char, c_ptr
+         character(kind=c_char), intent(in) :: id(*)
+         integer(c_int), value              :: nranks, rank
+         type(c_ptr), intent(out)           :: comm
+         integer(c_int)                     :: rc
+      end function
+
+      function OHXCommFree(comm) bind(C, name="OHXCommFree") result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: comm
+         integer(c_int)     :: rc
+      end function
+
+      function OHXShardRows(nrows_total, nranks, rank, row0, nrows) bind(C, name="OHXShardRows") result(rc)
+         import :: c_int, c_int64_t
+         integer(c_int64_t), value       :: nrows_total
+         integer(c_int), value           :: nranks, rank
+         integer(c_int64_t), intent(out) :: row0, nrows
+         integer(c_int)                  :: rc
+      end function
+
+      function OHXAllGatherOH(comm, d_shard, nrows_local, nrows_total, d_full, stream) &
+            bind(C, name="OHXAllGatherOH") result(rc)
+         import :: c_int, c_ptr, c_int64_t
+         type(c_ptr), value        :: comm, d_shard, d_full, stream
+         integer(c_int64_t), value :: nrows_local, nrows_total
          integer(c_int)            :: rc
       end function
 

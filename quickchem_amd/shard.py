@@ -87,8 +87,37 @@ def plan_pieces(n_local: int, max_pieces: int, granule: int, round_rows: int) ->
     return best
 
 
-def all_gather_chunk_async(out_full: torch.Tensor, out_local: torch.Tensor, lo: int, hi: int, n_local: int, world: int):
-    """Start gathering rows [lo, hi) of every rank's (equal-sized) shard straight into their
-    final places in `out_full`; returns the work handle (wait() before reading out_full)."""
-    views = [out_full[r * n_local + lo: r * n_local + hi] for r in range(world)]
-    return dist.all_gather(views, out_local[lo:hi], async_op=True)
+class ChunkGather:
+    """Gathers of the pieces of a shard, each overlapping the prediction of the next piece, ending with every
+    rank's rows at their place in `out_full` (row order).  A piece [lo, hi) of every rank's equal-sized shard is
+    gathered with ONE all_gather_into_tensor into a contiguous staging block [world][hi - lo] - the form RCCL writes
+    in place, with no flatten/copy-out hidden inside the backend - and a strided device copy puts it into
+    out_full[r * n_local + lo : r * n_local + hi] once the step's predictions are enqueued.  The copies move the
+    field once more (224 MB at C360, against 6 GB of features read per step); what they buy is that the
+    collectives run while the next piece is being walked."""
+
+    def __init__(self, out_full: torch.Tensor, n_local: int, world: int, pieces):
+        self.out_full, self.n_local, self.world = out_full, n_local, world
+        self.stage = [out_full.new_empty(world * (hi - lo)) for lo, hi in pieces]
+        self.pieces = list(pieces)
+        self.pending = []
+
+    def start(self, index: int, out_local: torch.Tensor):
+        """Call after piece `index` has been enqueued on the current stream."""
+        lo, hi = self.pieces[index]
+        src = out_local[lo:hi]
+        if dist.get_backend() == "gloo" and src.is_cuda:       # rehearsal on a shared GPU: gloo has no flat form there
+            n = hi - lo
+            work = dist.all_gather([self.stage[index][r * n:(r + 1) * n] for r in range(self.world)], src, async_op=True)
+        else:
+            work = dist.all_gather_into_tensor(self.stage[index], src, async_op=True)
+        self.pending.append((work, index))
+
+    def finish(self):
+        """Wait for the gathers and put the pieces at their rows; leaves the copies on the current stream."""
+        full = self.out_full[: self.world * self.n_local].view(self.world, self.n_local)
+        for work, index in self.pending:
+            work.wait()
+            lo, hi = self.pieces[index]
+            full[:, lo:hi].copy_(self.stage[index].view(self.world, hi - lo))
+        self.pending = []

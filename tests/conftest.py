@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# torch first: its wheel bundles its own HIP runtime under the same soname as /opt/rocm's, and the process ends up
+# with whichever is loaded first.  Loaded after libohxgb.so has pulled in the system one, torch.cuda reports no
+# device (seen on the GPU box when a test that only uses ctypes ran before the first torch test).
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

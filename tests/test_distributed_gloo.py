@@ -76,11 +76,21 @@ def _worker(rank, world, port, n_total, image_path, out_dir):
         if n_total % world == 0:
             # the overlapped form bench.py uses: pieces gathered asynchronously into their final places
             full2 = torch.zeros(n_total, dtype=torch.float32)
-            works = [shard.all_gather_chunk_async(full2, local, lo, hi, n, world)
-                     for lo, hi in shard.chunk_bounds(n, 3, 640)]
-            for w in works:
-                w.wait()
+            pieces = shard.chunk_bounds(n, 3, 640)
+            gather = shard.ChunkGather(full2, n, world, pieces)
+            for q in range(len(pieces)):
+                gather.start(q, local)
+            gather.finish()
             assert torch.equal(full2.view(torch.int32), full.view(torch.int32))
+            gather = shard.ChunkGather(full2.zero_(), n, world, pieces)          # a second step reuses the staging
+            for q in reversed(range(len(pieces))):
+                gather.start(q, local)
+            gather.finish()
+            assert torch.equal(full2.view(torch.int32), full.view(torch.int32))
+        # the C ABI's shard rule is the Python one (OHXShardRows: what a Fortran/MPI host would call)
+        from quickchem_amd import capi
+        for r in range(world):
+            assert capi.shard_rows(n_total, world, r) == shard.row_shard(n_total, world, r)
     finally:
         dist.destroy_process_group()
 

@@ -161,3 +161,31 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(tmp_path):
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["config"]["verified"] is True and line["n_gpus"] == 2 and line["config"]["grid_hint"] is True
+
+
+def test_native_all_gather_entry_points_on_one_rank():
+    """include/ohxgb.h part 4 with the one GPU of the box: RCCL is found and loaded by libohxgb.so itself, a
+    communicator of one rank is built from a unique id, and OHXAllGatherOH puts the shard at its rows - out of place
+    and in place.  (More than one rank needs more than one GPU: RCCL refuses two ranks on a device; the
+    sharding rule itself is covered on the CPU by tests/test_distributed_gloo.py.)"""
+    import torch
+    torch.cuda.set_device(0)
+    uid = capi.Communicator.unique_id()
+    assert len(uid) == capi.UNIQUE_ID_BYTES and any(uid)
+    comm = capi.Communicator(uid, 1, 0)
+    n = 1_000_003
+    shard = torch.arange(n, dtype=torch.float32, device="cuda")
+    full = torch.zeros(n, dtype=torch.float32, device="cuda")
+    comm.all_gather_oh(shard.data_ptr(), n, n, full.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(full, shard)
+    comm.all_gather_oh(full.data_ptr(), n, n, full.data_ptr())          # in place
+    torch.cuda.synchronize()
+    assert torch.equal(full, shard)
+    with pytest.raises(capi.OhxError, match="holds 5 rows"):
+        comm.all_gather_oh(shard.data_ptr(), 5, n, full.data_ptr())
+    with pytest.raises(capi.OhxError, match="rank < nranks"):
+        capi.Communicator(uid, 2, 2)
+    comm.free()
+    with pytest.raises(capi.OhxError, match="invalid or has been freed"):
+        capi.check(comm.lib, comm.lib.OHXAllGatherOH(0xDEAD0, None, 0, 0, None, None))

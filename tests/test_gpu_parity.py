@@ -449,3 +449,56 @@ def test_margin_of_a_non_identity_objective_starts_from_prob_to_margin(torch_cud
         gpu_predict(_json.dumps(doc).encode(), rows, cases["missing"], "super2", option_mask=1)
     leaves = gpu_predict(_json.dumps(doc).encode(), rows, cases["missing"], "wide", option_mask=16)
     assert np.array_equal(leaves.reshape(len(rows), -1), np.float32(cases["leaf_index"]))
+
+
+def test_rows_in_no_order_are_grouped_before_the_walk(torch_cuda, small_model, deep_model):
+    """Rows whose order says nothing (shuffled, or too few of a grid for a level size to show) go through the
+    clustering pass (csrc/cluster.hip): a key from the top of the first trees, a counting sort, and a walk through
+    the permutation.  Same margins bit for bit, whatever the key width, the row count, the missing values; rows
+    that ARE in grid order are recognised and left alone."""
+    torch = torch_cuda
+    grid = synth.GRIDS["C48"]
+    n = 400_000
+    rows = with_missing(synth.rows_cpu(grid, 123_456, n), 0.001)
+    rng = np.random.default_rng(5)
+    shuffled = rows[rng.permutation(n)]
+    want = helpers.oracle_predict(deep_model.image, shuffled, synth.XX_MISS)
+
+    def run(image, arr, params, rows_on_device=True):
+        b = capi.Booster(model_buffer=image)
+        for k, v in params.items():
+            b.set_param(k, v)
+        if not rows_on_device:
+            d = capi.DMatrix(arr, missing=synth.XX_MISS)
+            out = b.predict(d)
+            d.free()
+            return out, None
+        t = torch.from_numpy(arr).cuda()
+        d = capi.DMatrix(device_ptr=t.data_ptr(), nrow=arr.shape[0], ncol=arr.shape[1], missing=synth.XX_MISS)
+        out = torch.empty(arr.shape[0], dtype=torch.float32, device="cuda")
+        for _ in range(2):                                   # the second predict reuses the verdict, not the keys
+            out.zero_()
+            b.predict_device(d, out.data_ptr())
+            torch.cuda.synchronize()
+        b.check()
+        d.free()
+        return out.cpu().numpy(), b
+
+    for params in ({}, {"ohx_cluster": "on"}, {"ohx_cluster": "off"}, {"ohx_cluster": "on", "ohx_cluster_trees": 1, "ohx_cluster_steps": 1},
+                   {"ohx_cluster": "on", "ohx_cluster_trees": 8, "ohx_cluster_steps": 9},          # trimmed to 24 bits
+                   {"ohx_cluster": "on", "ohx_kernel": "super4"}, {"ohx_cluster": "on", "ohx_kernel": "packed2"}):
+        got, _ = run(deep_model.image, shuffled, params)
+        assert np.array_equal(helpers.bits(got), helpers.bits(want)), params
+    got, _ = run(deep_model.image, shuffled, {}, rows_on_device=False)      # the reference's own call sequence
+    assert np.array_equal(helpers.bits(got), helpers.bits(want))
+    # ragged sizes and tiny matrices, clustering forced
+    for m in (1, 63, 64, 65, 1000, 4097):
+        got, _ = run(small_model.image, shuffled[:m], {"ohx_cluster": "on"})
+        assert np.array_equal(helpers.bits(got), helpers.bits(helpers.oracle_predict(small_model.image, shuffled[:m], synth.XX_MISS))), m
+    # fewer columns than features, NaN as the missing marker
+    narrow = shuffled[:70_000, :20].copy()
+    b = capi.Booster(model_buffer=small_model.image)
+    b.set_param("ohx_cluster", "on")
+    d = capi.DMatrix(narrow, missing=float("nan"))
+    assert np.array_equal(helpers.bits(b.predict(d)), helpers.bits(helpers.oracle_predict(small_model.image, narrow, float("nan"))))
+    d.free()
