@@ -289,8 +289,9 @@ struct BoosterObj {
   // Run1: engineered features, OH_ML and the slab result stay in HBM between the steps
   DevBuf<float> d_run1[10];
   DevBuf<int32_t> d_slab;
-  // clustering pass for rows in no known order (cluster.hip)
-  DevBuf<uint32_t> d_cluster_keys, d_cluster_perm, d_cluster_counters, d_cluster_small;
+  // clustering pass for rows in no known order (kernels.hip)
+  DevBuf<uint32_t> d_cluster_keys[2], d_cluster_vals[2], d_cluster_small;
+  DevBuf<uint8_t> d_cluster_temp;
   PinnedBuf<uint32_t> h_cluster_small;
   std::vector<DevBuf<float>> d_run1_stage;
 };
@@ -506,7 +507,7 @@ void infer_level_size(DMatrixObj& d, hipStream_t stream) {
 }
 
 // Rows nobody has described and in which no level size was found: group them by the decisions they take at
-// the top of the booster's first trees (cluster.hip) and let every wave take 64 rows of one group.  Returns the
+// the top of the booster's first trees (kernels.hip) and let every wave take 64 rows of one group.  Returns the
 // permutation to walk through, or nullptr for "as they come".  Judged once per matrix (one wait on the stream,
 // like the level-size search): rows that mostly agree with their predecessor are in some useful order already.
 const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a, bool pred_leaf, KernelKind kind,
@@ -522,19 +523,20 @@ const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a,
   c.missing = d.missing;
   c.ntrees = (uint32_t)std::min<size_t>((size_t)std::max(b.tune.cluster_trees, 1), b.forest.trees.size());
   c.nsteps = (uint32_t)std::max(b.tune.cluster_steps, 1);
-  while (cluster_key_bits(c) > 24u && c.nsteps > 1) --c.nsteps;
-  while (cluster_key_bits(c) > 24u && c.ntrees > 1) --c.ntrees;
-  const size_t ncounters = std::max<size_t>((size_t)1 << cluster_key_bits(c), 4096);
-  b.d_cluster_keys.ensure(d.nrow);
-  b.d_cluster_perm.ensure(d.nrow);
-  b.d_cluster_counters.ensure(ncounters);
-  b.d_cluster_small.ensure(4096 + 1);
+  c.zorder = b.tune.cluster_zorder ? 1u : 0u;
+  c.ntrees = std::min<uint32_t>(c.ntrees, 4u);
+  while (cluster_key_bits(c) > 32u && c.nsteps > 1) --c.nsteps;
+  while (cluster_key_bits(c) > 32u && c.ntrees > 1) --c.ntrees;
+  const unsigned sort_bits = cluster_key_bits(c);
+  for (int q = 0; q < 2; ++q) {
+    b.d_cluster_keys[q].ensure(d.nrow);
+    b.d_cluster_vals[q].ensure(d.nrow);
+  }
+  b.d_cluster_small.ensure(1);
   b.h_cluster_small.ensure(1);
-  c.keys = b.d_cluster_keys.p;
-  c.perm = b.d_cluster_perm.p;
-  c.counters = b.d_cluster_counters.p;
-  c.agree = b.d_cluster_small.p + 4096;
-  HIP_CHECK(hipMemsetAsync(c.counters, 0, ncounters * sizeof(uint32_t), stream));
+  c.keys = b.d_cluster_keys[0].p;
+  c.vals = b.d_cluster_vals[0].p;
+  c.agree = b.d_cluster_small.p;
   HIP_CHECK(hipMemsetAsync(c.agree, 0, sizeof(uint32_t), stream));
   HIP_CHECK(launch_cluster_keys(device_forest(b), c, b.dev.num_cus, stream));
   if (b.tune.cluster < 0 && !d.cluster_decided) {
@@ -543,12 +545,18 @@ const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a,
     d.cluster_decided = true;
     d.cluster_on = (double)b.h_cluster_small.p[0] < 0.5 * (double)d.nrow;
     if (getenv("OHX_DEBUG"))
-      fprintf(stderr, "[libohxgb] cluster verdict: %u of %llu rows agree with their predecessor on the first tree's key -> %s\n",
+      fprintf(stderr, "[libohxgb] cluster verdict: %u of %llu rows agree with their predecessor on the first three decisions -> %s\n",
               b.h_cluster_small.p[0], (unsigned long long)d.nrow, d.cluster_on ? "cluster" : "leave");
     if (!d.cluster_on) return nullptr;
   }
-  HIP_CHECK(launch_cluster_sort(c, b.d_cluster_small.p, b.dev.num_cus, stream));
-  return c.perm;
+  size_t temp_bytes = 0;
+  HIP_CHECK(sort_pairs_u32(nullptr, &temp_bytes, c.keys, b.d_cluster_keys[1].p, c.vals, b.d_cluster_vals[1].p, d.nrow,
+                           sort_bits, stream, nullptr));
+  b.d_cluster_temp.ensure(temp_bytes);
+  uint32_t* sorted = nullptr;
+  HIP_CHECK(sort_pairs_u32(b.d_cluster_temp.p, &temp_bytes, c.keys, b.d_cluster_keys[1].p, c.vals, b.d_cluster_vals[1].p,
+                           d.nrow, sort_bits, stream, &sorted));
+  return sorted;
 }
 
 void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsigned ntree_limit, float* d_out,
@@ -882,10 +890,10 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     else throw OhxError("ohx_cluster must be auto, on or off");
   } else if (n == "ohx_cluster_trees") {
     b->tune.cluster_trees = std::max(1, atoi(value));
+  } else if (n == "ohx_cluster_zorder") {
+    b->tune.cluster_zorder = atoi(value) != 0;
   } else if (n == "ohx_cluster_steps") {
     b->tune.cluster_steps = std::max(1, atoi(value));
-  } else if (n == "ohx_tree_sync") {
-    b->tune.tree_sync = atoi(value) > 0 ? atoi(value) : 0;
   } else if (n == "ohx_lds_pad") {
     b->tune.lds_pad = atoi(value);
   } else if (n == "ohx_prefetch") {

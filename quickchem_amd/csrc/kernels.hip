@@ -304,7 +304,7 @@ constexpr uint32_t kFirstBytes = kFirstTrees * 2 * 16;
 template <int CHAINS, bool HAS_MISSING>
 __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const SuperTreeHead* __restrict__ heads,
                                             uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile,
-                                            const char* __restrict__ first, uint32_t nfirst, uint32_t sync_every) {
+                                            const char* __restrict__ first, uint32_t nfirst) {
   if (t0 >= t1) return acc;
   const lds_cptr first_lds = (lds_cptr)first;
   const u32x4* __restrict__ nodes_v = reinterpret_cast<const u32x4*>(nodes);
@@ -313,14 +313,7 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
   SuperTreeHead hn[CHAINS];
 #pragma unroll
   for (int c = 0; c < CHAINS; ++c) hn[c] = heads[(t0 + c < t1) ? t0 + c : t1 - 1];
-  uint32_t until_sync = sync_every;
   for (uint32_t t = t0; t < t1; t += CHAINS) {
-    // experiment knob (ohx_tree_sync): the waves of a block meet every `sync_every` groups of trees, so that
-    // four neighbouring bricks ask the L1 for the same tree's lines at the same time
-    if (sync_every != 0u && --until_sync == 0u) {
-      __builtin_amdgcn_s_barrier();
-      until_sync = sync_every;
-    }
     SuperTreeHead h[CHAINS];
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) {
@@ -377,7 +370,7 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 template <int FMT, int CHAINS>
 __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads, uint32_t t0,
                                            uint32_t t1, const float* tile, bool wave_has_missing, const char* first,
-                                           uint32_t nfirst, uint32_t sync_every = 0u) {
+                                           uint32_t nfirst) {
   float acc = fr.base_score;
   if constexpr (FMT == 1) {
     const __amdgpu_buffer_rsrc_t nodes = make_rsrc(fr.packed, fr.packed_bytes);
@@ -386,8 +379,8 @@ __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTr
   } else if constexpr (FMT == 2) {
     // plain 128-bit global loads: measured 8 % faster than buffer loads on the divergent deep levels
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.super);
-    return wave_has_missing ? walk_super<CHAINS, true>(nodes, heads, t0, t1, acc, tile, first, nfirst, sync_every)
-                            : walk_super<CHAINS, false>(nodes, heads, t0, t1, acc, tile, first, nfirst, sync_every);
+    return wave_has_missing ? walk_super<CHAINS, true>(nodes, heads, t0, t1, acc, tile, first, nfirst)
+                            : walk_super<CHAINS, false>(nodes, heads, t0, t1, acc, tile, first, nfirst);
   } else {
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
     return wave_has_missing ? walk_wide_tile<true>(nodes, fr.roots, t0, t1, acc, tile)
@@ -436,8 +429,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const uint64_t wave_id = (uint64_t)block * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
-  // barriers need every wave of the block to make the same number of walks: whole rounds of the grid only
-  const uint32_t sync_every = (a.sync_every > 0 && (a.tile_end - a.tile_begin) % nwaves == 0) ? (uint32_t)a.sync_every : 0u;
   if constexpr (PREFETCH27) {
     uint64_t tile_id = a.tile_begin + wave_id;
     Row27 regs;
@@ -457,9 +448,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
         load_row27(regs, a.rows, valid ? row : 0);   // in flight during the walk
       }
       const bool wave_nan = __any(lane_nan);
-      // (a block whose waves disagree about missing values would meet at different barriers: no sync then)
-      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst,
-                                               a.has_missing_hint ? 0u : sync_every);
+      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
       if (this_valid) __builtin_nontemporal_store(acc, out + this_row);
       tile_id = next;
     }
@@ -515,10 +504,12 @@ __global__ __launch_bounds__(kBlock) void predict_rows_direct_kernel(DeviceFores
 // The fused path: reads the MAPL fields in place (lane = consecutive i, coalesced),
 // applies PL/100 (OH_GridCompMod.F90:314), walks, writes 10**pred * OHscale
 // (OH_GridCompMod.F90:369,1569) into OH_ML(i,j,k1..k2).
-template <int FMT, int CHAINS>
-__global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr, FieldsArgs a, const SuperTreeHead* __restrict__ heads,
-                                                                float* __restrict__ out,
-                                                                float* __restrict__ margin_out) {
+// PREFETCH27: the OH shape (27 fields, 27 features): the next tile's 27 field values are already in flight into
+// registers while the current tile is walked, as in predict_rows_tile_kernel.
+template <int FMT, int CHAINS, bool PREFETCH27>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS > 5 ? 4 : 5))) void predict_fields_kernel(
+    DeviceForest fr, FieldsArgs a, const SuperTreeHead* __restrict__ heads, float* __restrict__ out,
+    float* __restrict__ margin_out) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -533,6 +524,58 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
   const uint64_t wave_id = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
   const float qnan = __builtin_nanf("");
+  auto finish = [&](float acc, uint64_t m, bool valid) {
+    if (!valid) return;
+    if (margin_out) margin_out[m] = acc;
+    float oh = acc;
+    // 10.0**x rounded once from double: agrees with a correctly rounded powf
+    if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);
+    oh = oh * a.scale;
+    out[slab_out + m] = oh;
+  };
+  if constexpr (PREFETCH27) {
+    float regs[27];
+    auto load27 = [&](uint64_t m, uint64_t col, bool valid) {
+#pragma unroll
+      for (int f = 0; f < 27; ++f) {
+        const uint64_t at = ((a.is2d_mask >> f) & 1u) ? col : slab + m;
+        regs[f] = __builtin_nontemporal_load(a.field[f] + (valid ? at : 0));
+      }
+    };
+    uint64_t tile_id = a.tile_begin + wave_id;
+    bool valid = false;
+    uint64_t m = 0;
+    if (tile_id < a.tile_end) {
+      m = tile_row(a.shape, tile_id, lane, nrow, &valid);
+      load27(m, valid ? m % plane : 0, valid);
+    }
+    while (tile_id < a.tile_end) {
+      bool lane_nan = false, any_inf = false;
+#pragma unroll
+      for (int f = 0; f < 27; ++f) {
+        float x = regs[f];
+        if ((uint32_t)f == a.pl_feature) x = x / 100.0f;
+        any_inf |= is_inf(x);
+        if (!missing_is_nan && x == a.missing) x = qnan;
+        if (!valid) x = 0.0f;
+        lane_nan |= (x != x);
+        tile[f * kWave] = x;
+      }
+      if (valid && any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
+      const uint64_t next = tile_id + nwaves;
+      const uint64_t this_m = m;
+      const bool this_valid = valid;
+      if (next < a.tile_end) {
+        m = tile_row(a.shape, next, lane, nrow, &valid);
+        load27(m, valid ? m % plane : 0, valid);                 // in flight during the walk
+      }
+      const bool wave_nan = __any(lane_nan);
+      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
+      finish(acc, this_m, this_valid);
+      tile_id = next;
+    }
+    return;
+  }
   for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
     bool valid;
     const uint64_t m = tile_row(a.shape, tile_id, lane, nrow, &valid);
@@ -554,14 +597,7 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
     if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
     const bool wave_nan = __any(lane_nan);
     const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
-    if (valid) {
-      if (margin_out) margin_out[m] = acc;
-      float oh = acc;
-      // 10.0**x rounded once from double: agrees with a correctly rounded powf
-      if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);
-      oh = oh * a.scale;
-      out[slab_out + m] = oh;
-    }
+    finish(acc, m, valid);
   }
 }
 
@@ -606,6 +642,146 @@ __global__ __launch_bounds__(kBlock) void detect_period_kernel(const float* __re
   if (threadIdx.x == 0) bad |= bits[col] != bits[period * ncol + col] ||
                                bits[(span - 1) * ncol + col] != bits[(nrow - 1) * ncol + col];
   if (bad) atomicOr(slot, 1u);
+}
+
+// ------------------------------------------------------------------ rows nobody can describe: clustering pass
+//
+// What a tree walk costs on gfx950 is set by how many different node lines the lanes of a wave - and above
+// all the four lanes of a quad - ask for.  Rows that come in grid order are tiled into bricks of
+// neighbouring gridcells; rows in no particular order (a caller that shuffled, filtered or concatenated its
+// gather: the DMatrix contract allows any order, OH_GridCompMod.F90:275-345 is just one caller) have no
+// neighbours to offer, and 64 arbitrary rows per wave run at a third of the speed.  This pass finds them
+// neighbours: every row gets a key made of the decisions it takes at the top of the first few trees of the
+// booster itself, (key, row number) pairs are sorted by key (a device radix sort, sort_pairs.hip), and the walk
+// then takes 64 rows that are neighbours in key order per wave through the sorted row numbers.  Predictions cannot change - rows are independent and
+// every row still walks every tree in order; only which rows share a wave does.
+//
+// All of it is plain integer work next to the walk: one more read of the rows and a sort of eight bytes per row.
+// One lane = one row.  The wave's rows go through the same LDS tile as in the walk (coalesced row loads, missing ->
+// NaN), the key walk reads its features from there.  Key = for each of `ntrees` trees the root decision (trees
+// whose super-nodes start below the root) and two decisions per super-node step, most significant first; a row
+// that reaches a leaf early keeps walking on fixed decisions.  zorder: the trees' decisions interleaved step by
+// step instead of tree after tree.  Also counts how many rows agree with the row before them on the first three
+// decisions of the first tree: rows in grid order mostly do (74 % on the C360 batch), shuffled rows mostly do
+// not (21 %).
+constexpr int kKeyTileStride = kWave + 1;
+
+// NT = number of trees in the key (compile time: their walks are independent chains and must be in flight together)
+template <int NT>
+__global__ __launch_bounds__(kBlock) void cluster_keys_kernel(DeviceForest fr, ClusterArgs a) {
+  extern __shared__ float lds[];
+  const u32x4* __restrict__ nodes = reinterpret_cast<const u32x4*>(fr.super);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  float* wave_tile = lds + (size_t)wave * fr.num_feature * kKeyTileStride;
+  float* tile = wave_tile + lane;
+  const bool missing_is_nan = a.missing != a.missing;
+  const uint64_t ntiles = (a.nrow + kWave - 1) / kWave;
+  const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  SuperTreeHead h[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) h[t] = fr.super_heads[t];
+  uint32_t agree = 0;
+  for (uint64_t tile_id = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile_id < ntiles; tile_id += nwaves) {
+    const uint64_t row = tile_id * kWave + lane;
+    const bool valid = row < a.nrow;
+    // The wave's 64 rows are one contiguous piece of the matrix: stream it in coalesced (lane l takes elements l,
+    // l + 64, ...) and drop every element at [feature][row] of the tile.  Row-per-lane loads (as the walk kernels
+    // do, hidden behind the walk there) touch every line seven times and run this pass at 0.8 TB/s.  The tile rows
+    // are 65 floats apart so that consecutive elements - consecutive features of one row - fall in different banks.
+    {
+      const uint64_t first_row = tile_id * kWave;
+      const uint32_t rows_here = (uint32_t)((a.nrow - first_row) < (uint64_t)kWave ? (a.nrow - first_row) : (uint64_t)kWave);
+      const uint32_t count = rows_here * a.ncol;
+      const float* base = a.rows + first_row * (uint64_t)a.ncol;
+      const uint32_t dr = (uint32_t)kWave / a.ncol, df = (uint32_t)kWave % a.ncol;
+      uint32_t r = (uint32_t)lane / a.ncol, f = (uint32_t)lane % a.ncol;
+      for (uint32_t e = (uint32_t)lane; e < count; e += kWave) {
+        float x = __builtin_nontemporal_load(base + e);
+        if (!missing_is_nan && x == a.missing) x = __builtin_nanf("");
+        wave_tile[f * kKeyTileStride + r] = x;
+        r += dr;
+        f += df;
+        if (f >= a.ncol) {
+          f -= a.ncol;
+          r += 1;
+        }
+      }
+      // features the matrix does not have are missing; rows past the end are never looked at
+      for (uint32_t ff = a.ncol; ff < fr.num_feature; ++ff) tile[ff * kKeyTileStride] = __builtin_nanf("");
+    }
+    // lanes read what other lanes of the same wave wrote: LDS serves a wave's instructions in order, the fence
+    // and the wave barrier keep the compiler from moving the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t key = 0, lead = 0;
+    uint32_t rel[NT], part[NT];
+    u32x4 nd[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      rel[t] = 4u;
+      part[t] = 0;
+      if (h[t].root_meta & 0x100u) {        // phase 1: the root is evaluated from the head
+        const float x = tile[(h[t].root_meta & 31u) * kKeyTileStride];
+        const bool l = (x != x) ? (h[t].root_meta & 32u) != 0u : x < h[t].root_thr;
+        part[t] = l ? 0u : 1u;
+        rel[t] = 4u + (l ? 0u : 1u);
+      }
+      nd[t] = nodes[h[t].base + rel[t]];
+    }
+    for (uint32_t s = 0; s < a.nsteps; ++s) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        uint32_t bits = 0;
+        if (s < h[t].steps) {
+          const uint32_t w = nd[t].w;
+          const uint32_t f0 = (w >> 8) & 31u;
+          if (f0 != kSuperLeaf) {
+            const float x0 = tile[f0 * kKeyTileStride];
+            const bool l0 = (x0 != x0) ? (w & 32u) != 0u : x0 < __uint_as_float(nd[t].x);
+            const uint32_t f1 = (w >> (l0 ? 0u : 13u)) & 31u;
+            bool l1 = true;
+            if (f1 != kSuperLeaf) {
+              const float x1 = tile[f1 * kKeyTileStride];
+              l1 = (x1 != x1) ? (w & (l0 ? 64u : 128u)) != 0u : x1 < __uint_as_float(l0 ? nd[t].y : nd[t].z);
+            }
+            bits = (l0 ? 0u : 2u) | (l1 ? 0u : 1u);
+            rel[t] = ((w >> 18) << 2) + bits;
+          } else {
+            rel[t] = (w >> 18) << 2;        // fillers lead to fillers
+          }
+        }
+        part[t] = (part[t] << 2) | bits;
+        if (a.zorder) key = (key << 2) | bits;
+      }
+      if (s + 1 < a.nsteps) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (s + 1 < h[t].steps) nd[t] = nodes[h[t].base + rel[t]];
+      }
+      if (s == 0) lead = part[0];            // root and first step of the first tree: 3 decisions
+    }
+    if (a.zorder) {
+      uint32_t roots = 0;                    // the root decisions in front of the interleaved steps
+#pragma unroll
+      for (int t = 0; t < NT; ++t) roots = (roots << 1) | (part[t] >> (2u * a.nsteps));
+      key |= roots << (2u * a.nsteps * NT);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) key = (key << (1u + 2u * a.nsteps)) | part[t];
+    }
+    if (valid) {
+      a.keys[row] = key;
+      a.vals[row] = (uint32_t)row;
+    }
+    // neighbours in row order: lane l against lane l - 1 (the first lane of a wave sits out)
+    const uint32_t prev = __shfl_up(lead, 1);
+    const bool same = valid && lane != 0 && prev == lead;
+    agree += __popcll(__ballot(same));
+    __builtin_amdgcn_wave_barrier();         // the next tile overwrites what this one's lanes were reading
+  }
+  if (lane == 0 && agree) atomicAdd(a.agree, agree);
 }
 
 // ------------------------------------------------------------------ OH Run1: before and after the predict
@@ -794,7 +970,6 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
   const uint64_t ntiles = a.shape.ntiles(a.nrow);
   const int grid = tile_grid(kernel, lds, ntiles, num_cus);
   a.xcd_remap = tune.xcd_remap;
-  a.sync_every = tune.tree_sync;
   if (tune.launches_per_residency <= 0) {
     a.tile_begin = 0;
     a.tile_end = ntiles;
@@ -904,8 +1079,11 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
   const bool use_wide = kind == KernelKind::Wide || (!is_super && fr.packed == nullptr);
   if (use_wide && fr.wide == nullptr) return hipErrorInvalidValue;
-#define OHX_LAUNCH_FIELDS(FMT, CH) \
-  return launch_fields_tiled(predict_fields_kernel<FMT, CH>, lds, fr, a, nrow, num_cus, stream, tune)
+  // the OH shape, and every wave gets more than one tile per launch: prefetch the next tile's fields
+  const bool pf = a.nfield == 27 && fr.num_feature == 27 && tune.launches_per_residency != 1 && tune.prefetch;
+#define OHX_LAUNCH_FIELDS(FMT, CH)                                                                                      \
+  return pf ? launch_fields_tiled(predict_fields_kernel<FMT, CH, true>, lds, fr, a, nrow, num_cus, stream, tune)         \
+            : launch_fields_tiled(predict_fields_kernel<FMT, CH, false>, lds, fr, a, nrow, num_cus, stream, tune)
   if (use_wide) OHX_LAUNCH_FIELDS(0, 1);
   switch (kind) {
     case KernelKind::Packed1: OHX_LAUNCH_FIELDS(1, 1);
@@ -919,6 +1097,32 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
     default: OHX_LAUNCH_FIELDS(2, 2);
   }
 #undef OHX_LAUNCH_FIELDS
+}
+
+uint32_t cluster_key_bits(const ClusterArgs& a) { return a.ntrees * (1u + 2u * a.nsteps); }
+
+template <int NT>
+hipError_t launch_cluster_keys_nt(const DeviceForest& fr, const ClusterArgs& a, size_t lds, int num_cus, hipStream_t stream) {
+  hipError_t e = ensure_lds(cluster_keys_kernel<NT>, lds);
+  if (e != hipSuccess) return e;
+  const int grid = tile_grid(cluster_keys_kernel<NT>, lds, (a.nrow + kWave - 1) / kWave, num_cus);
+  hipLaunchKernelGGL(cluster_keys_kernel<NT>, dim3(grid), dim3(kBlock), lds, stream, fr, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_cluster_keys(const DeviceForest& fr, const ClusterArgs& a, int num_cus, hipStream_t stream) {
+  if (a.nrow == 0) return hipSuccess;
+  if (fr.super == nullptr || cluster_key_bits(a) > 32u || a.ntrees == 0 || a.ntrees > 4 || a.ntrees > fr.num_trees ||
+      a.ncol > fr.num_feature)
+    return hipErrorInvalidValue;
+  const size_t lds = (size_t)kWavesPerBlock * fr.num_feature * kKeyTileStride * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  switch (a.ntrees) {
+    case 1: return launch_cluster_keys_nt<1>(fr, a, lds, num_cus, stream);
+    case 2: return launch_cluster_keys_nt<2>(fr, a, lds, num_cus, stream);
+    case 3: return launch_cluster_keys_nt<3>(fr, a, lds, num_cus, stream);
+    default: return launch_cluster_keys_nt<4>(fr, a, lds, num_cus, stream);
+  }
 }
 
 hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_t stream) {

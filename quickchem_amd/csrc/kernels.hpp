@@ -91,9 +91,7 @@ struct PredictArgs {
   uint64_t tile_begin = 0;      // first 64-row tile of this launch (tile kernels)
   uint64_t tile_end = 0;        // one past the last tile of this launch
   int xcd_remap = 1;            // give each XCD a contiguous range of tiles
-  const uint32_t* perm = nullptr;  // rows grouped by cluster.hip: lane l of tile t takes row perm[64 t + l]
-  int sync_every = 0;           // experiment: waves of a block meet at a barrier every this many tree groups
-  int has_missing_hint = 0;     // (set by the launcher when the batch may hold missing values: no barriers)
+  const uint32_t* perm = nullptr;  // rows grouped by the clustering pass: lane l of tile t takes row perm[64 t + l]
   TileShape shape;              // lanes -> rows
 };
 
@@ -105,10 +103,9 @@ struct LaunchTuning {
   int xcd_remap = 1;
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
-  int tree_sync = 0;  // experiment knob: block-level barrier every this many tree groups (0 = never)
   // rows in no known order: -1 = decide per matrix (cluster unless the rows look ordered), 0 = never, 1 = always
   int cluster = -1;
-  int cluster_trees = 3, cluster_steps = 3;
+  int cluster_trees = 2, cluster_steps = 7, cluster_zorder = 0;
   // rows API: the grid the rows were gathered from and the grid row the matrix starts at
   // (XGBoosterSetParam "ohx_grid" = "im,jm[,row0]").  0 = unknown, tiles are 64 consecutive rows.
   int grid_im = 0, grid_jm = 0;
@@ -177,22 +174,24 @@ hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_
 hipError_t launch_k_slab(const SlabArgs& a, hipStream_t stream);
 hipError_t launch_post_process(const PostArgs& a, hipStream_t stream);
 
-// The clustering pass in front of the walk for rows in no known order (cluster.hip).  Device pointers.
+// The clustering pass in front of the walk for rows in no known order (kernels.hip).  Device pointers.
 struct ClusterArgs {
   const float* rows = nullptr;
   uint64_t nrow = 0;
   uint32_t ncol = 0;
   float missing = 0.0f;
-  uint32_t ntrees = 3, nsteps = 3;   // key = top of the first `ntrees` trees, `nsteps` super-node steps each (<= 24 bits)
+  uint32_t ntrees = 2, nsteps = 7;   // key = top of the first `ntrees` (<= 4) trees, `nsteps` super-node steps each (<= 32 bits)
+  uint32_t zorder = 0;               // interleave the trees' decisions step by step instead of tree after tree
   uint32_t* keys = nullptr;          // [nrow]
-  uint32_t* counters = nullptr;      // [max(2**bits, 4096)], zero before launch_cluster_keys; cursors afterwards
-  uint32_t* perm = nullptr;          // [nrow] row numbers grouped by key
-  uint32_t* agree = nullptr;         // one word, zero before: rows whose first-tree key equals the previous row's
+  uint32_t* vals = nullptr;          // [nrow] the row numbers 0 .. nrow-1, to be sorted along with the keys
+  uint32_t* agree = nullptr;         // one word, zero before: rows whose first three decisions equal the previous row's
 };
 uint32_t cluster_key_bits(const ClusterArgs& a);
 hipError_t launch_cluster_keys(const DeviceForest& forest, const ClusterArgs& a, int num_cus, hipStream_t stream);
-// d_block_sums: [4096] scratch words
-hipError_t launch_cluster_sort(const ClusterArgs& a, uint32_t* d_block_sums, int num_cus, hipStream_t stream);
+// (key, value) pairs sorted by the low `key_bits` bits of the key.  Called with temp == nullptr it only reports
+// the scratch bytes needed in *temp_bytes.  *sorted_vals = whichever of vals_a / vals_b holds the result.
+hipError_t sort_pairs_u32(void* temp, size_t* temp_bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
+                          uint32_t* vals_b, uint64_t n, unsigned key_bits, hipStream_t stream, uint32_t** sorted_vals);
 
 enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super3, Super4, Super5, Super6 };
 

@@ -453,7 +453,7 @@ def test_margin_of_a_non_identity_objective_starts_from_prob_to_margin(torch_cud
 
 def test_rows_in_no_order_are_grouped_before_the_walk(torch_cuda, small_model, deep_model):
     """Rows whose order says nothing (shuffled, or too few of a grid for a level size to show) go through the
-    clustering pass (csrc/cluster.hip): a key from the top of the first trees, a counting sort, and a walk through
+    clustering pass (csrc/kernels.hip): a key from the top of the first trees, a counting sort, and a walk through
     the permutation.  Same margins bit for bit, whatever the key width, the row count, the missing values; rows
     that ARE in grid order are recognised and left alone."""
     torch = torch_cuda
@@ -485,7 +485,8 @@ def test_rows_in_no_order_are_grouped_before_the_walk(torch_cuda, small_model, d
         return out.cpu().numpy(), b
 
     for params in ({}, {"ohx_cluster": "on"}, {"ohx_cluster": "off"}, {"ohx_cluster": "on", "ohx_cluster_trees": 1, "ohx_cluster_steps": 1},
-                   {"ohx_cluster": "on", "ohx_cluster_trees": 8, "ohx_cluster_steps": 9},          # trimmed to 24 bits
+                   {"ohx_cluster": "on", "ohx_cluster_trees": 8, "ohx_cluster_steps": 9},          # trimmed to 4 trees, 32 bits
+                   {"ohx_cluster": "on", "ohx_cluster_trees": 3, "ohx_cluster_steps": 4, "ohx_cluster_zorder": 1},
                    {"ohx_cluster": "on", "ohx_kernel": "super4"}, {"ohx_cluster": "on", "ohx_kernel": "packed2"}):
         got, _ = run(deep_model.image, shuffled, params)
         assert np.array_equal(helpers.bits(got), helpers.bits(want)), params

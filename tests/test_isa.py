@@ -1,0 +1,54 @@
+"""Guards on the generated gfx950 code of the walk (CPU: hipcc cross-compiles).  Each of these was once lost
+without a test noticing, and each costs measurable time on the MI355X (profiles/r02_sweeps.txt):
+  * the block's first-step table must be read with ds_read_b128; when hipcc loses the LDS address space of the
+    pointer it emits flat_load_dwordx4 and every tree's first step goes through the texture addresser (+3.8 %);
+  * no scratch (spills) and at most 84 VGPRs in the default kernel, or a CU holds fewer than 20 waves;
+  * super-nodes are fetched as ONE global_load_dwordx4 each (hipcc likes to split the vector, twice the gathers)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from tests import helpers
+
+HIPCC = "/opt/rocm/bin/hipcc"
+DEFAULT_KERNEL = "predict_rows_tile_kernelILi2ELi2ELb1E"
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "kernels.s"
+    src = os.path.join(helpers.ROOT, "quickchem_amd", "csrc", "kernels.hip")
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
+                        src, "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read()
+
+
+def kernel_body(text, name_part):
+    m = re.search(r"^(_Z\w*" + re.escape(name_part) + r"\w*):\s*; @\1\n(.*?)^\s*\.end_amdhsa_kernel", text, re.S | re.M)
+    assert m, name_part
+    return m.group(2)
+
+
+def test_no_flat_loads_and_no_scratch_anywhere(isa):
+    assert "flat_load" not in isa and "flat_store" not in isa
+    assert "scratch_load" not in isa and "scratch_store" not in isa
+
+
+def test_default_walk_kernel_shape(isa):
+    body = kernel_body(isa, DEFAULT_KERNEL)
+    assert body.count("ds_read_b128") >= 4                      # first-step table: two chains x with/without missing values
+    assert body.count("global_load_dwordx4") >= 16
+    vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", body).group(1))
+    assert vgpr <= 84, vgpr                                     # 6 waves per SIMD leave 85
+    assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", body).group(1)) == 0
+
+
+def test_fields_kernel_reads_its_table_from_lds_too(isa):
+    body = kernel_body(isa, "predict_fields_kernelILi2ELi2ELb1E")
+    assert body.count("ds_read_b128") >= 4

@@ -1,10 +1,11 @@
 #!/bin/bash
 # usage: tools/profile_round.sh <round tag>   (run on the GPU box through gpurun)
 # Produces, under gpurun_out/profile_<tag>/, what profiles/ keeps for the round:
-#   kernel_stats.csv     rocprofv3 --kernel-trace --stats of the default `python3 bench.py`
-#   bench.json           the JSON line of that same command
-#   pmc_summary.txt      per-step means of the predict kernel's counters (separate --pmc passes)
-#   calib_*.txt          FETCH_SIZE calibration on an almost pure streaming run (1 tree)
+#   kernel_stats.csv        rocprofv3 --kernel-trace --stats of the default `python3 bench.py`
+#   bench.json              the JSON line of that same command;  bench_plain.json the same without the profiler
+#   pmc_summary.txt         per-step means of the predict kernel's counters (separate --pmc passes, tools/pmc.sh)
+#   calib_fetch_write.txt   FETCH_SIZE calibration on an almost pure streaming run (1 tree of depth 0)
+#   traffic.json            roofline.traffic for bench.py, tagged with the hash of the kernel sources it was measured on
 tag=$1
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/profile_$tag && mkdir -p $O && cd $R
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py > $O/bench_under_rocprof.log 2>&1
@@ -12,10 +13,10 @@ tail -1 $O/bench_under_rocprof.log > $O/bench.json
 cp $O/trace/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 timeout -k 10 600 python3 bench.py > $O/bench_plain.log 2>&1
 tail -1 $O/bench_plain.log > $O/bench_plain.json
-tools/pmc.sh $tag > /dev/null 2>&1
+tools/pmc.sh $tag --no-verify > /dev/null 2>&1
 cp gpurun_out/pmc_$tag/summary.txt $O/pmc_summary.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/calib_$c -- python3 bench.py --cpu-seconds 0 --steps 2 --warmup 1 --trees 1 --depth 0 > $O/calib_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/calib_$c -- python3 bench.py --cpu-seconds 0 --no-verify --steps 2 --warmup 1 --trees 1 --depth 0 > $O/calib_$c.log 2>&1
 done
 python3 - $O <<'PY'
 import csv, glob, sys
@@ -30,5 +31,6 @@ with open(O + '/calib_fetch_write.txt', 'w') as out:
         line = f"{c} per_step={tot/3:.6g} (1 tree of depth 0: rows 6 046 617 600 B read, 223 948 800 B written per step)"
         print(line); out.write(line + "\n")
 PY
+python3 tools/make_traffic_json.py $O/pmc_summary.txt $O/calib_fetch_write.txt $O/bench_plain.json > $O/traffic.json
 rm -rf $O/trace $O/calib_FETCH_SIZE $O/calib_WRITE_SIZE
 ls -la $O
