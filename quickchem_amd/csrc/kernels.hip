@@ -504,12 +504,10 @@ __global__ __launch_bounds__(kBlock) void predict_rows_direct_kernel(DeviceFores
 // The fused path: reads the MAPL fields in place (lane = consecutive i, coalesced),
 // applies PL/100 (OH_GridCompMod.F90:314), walks, writes 10**pred * OHscale
 // (OH_GridCompMod.F90:369,1569) into OH_ML(i,j,k1..k2).
-// PREFETCH27: the OH shape (27 fields, 27 features): the next tile's 27 field values are already in flight into
-// registers while the current tile is walked, as in predict_rows_tile_kernel.
-template <int FMT, int CHAINS, bool PREFETCH27>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS > 5 ? 4 : 5))) void predict_fields_kernel(
-    DeviceForest fr, FieldsArgs a, const SuperTreeHead* __restrict__ heads, float* __restrict__ out,
-    float* __restrict__ margin_out) {
+template <int FMT, int CHAINS>
+__global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr, FieldsArgs a, const SuperTreeHead* __restrict__ heads,
+                                                                float* __restrict__ out,
+                                                                float* __restrict__ margin_out) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -524,58 +522,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   const uint64_t wave_id = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
   const float qnan = __builtin_nanf("");
-  auto finish = [&](float acc, uint64_t m, bool valid) {
-    if (!valid) return;
-    if (margin_out) margin_out[m] = acc;
-    float oh = acc;
-    // 10.0**x rounded once from double: agrees with a correctly rounded powf
-    if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);
-    oh = oh * a.scale;
-    out[slab_out + m] = oh;
-  };
-  if constexpr (PREFETCH27) {
-    float regs[27];
-    auto load27 = [&](uint64_t m, uint64_t col, bool valid) {
-#pragma unroll
-      for (int f = 0; f < 27; ++f) {
-        const uint64_t at = ((a.is2d_mask >> f) & 1u) ? col : slab + m;
-        regs[f] = __builtin_nontemporal_load(a.field[f] + (valid ? at : 0));
-      }
-    };
-    uint64_t tile_id = a.tile_begin + wave_id;
-    bool valid = false;
-    uint64_t m = 0;
-    if (tile_id < a.tile_end) {
-      m = tile_row(a.shape, tile_id, lane, nrow, &valid);
-      load27(m, valid ? m % plane : 0, valid);
-    }
-    while (tile_id < a.tile_end) {
-      bool lane_nan = false, any_inf = false;
-#pragma unroll
-      for (int f = 0; f < 27; ++f) {
-        float x = regs[f];
-        if ((uint32_t)f == a.pl_feature) x = x / 100.0f;
-        any_inf |= is_inf(x);
-        if (!missing_is_nan && x == a.missing) x = qnan;
-        if (!valid) x = 0.0f;
-        lane_nan |= (x != x);
-        tile[f * kWave] = x;
-      }
-      if (valid && any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
-      const uint64_t next = tile_id + nwaves;
-      const uint64_t this_m = m;
-      const bool this_valid = valid;
-      if (next < a.tile_end) {
-        m = tile_row(a.shape, next, lane, nrow, &valid);
-        load27(m, valid ? m % plane : 0, valid);                 // in flight during the walk
-      }
-      const bool wave_nan = __any(lane_nan);
-      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
-      finish(acc, this_m, this_valid);
-      tile_id = next;
-    }
-    return;
-  }
   for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
     bool valid;
     const uint64_t m = tile_row(a.shape, tile_id, lane, nrow, &valid);
@@ -597,7 +543,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
     if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
     const bool wave_nan = __any(lane_nan);
     const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
-    finish(acc, m, valid);
+    if (valid) {
+      if (margin_out) margin_out[m] = acc;
+      float oh = acc;
+      // 10.0**x rounded once from double: agrees with a correctly rounded powf
+      if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);
+      oh = oh * a.scale;
+      out[slab_out + m] = oh;
+    }
   }
 }
 
@@ -1079,11 +1032,8 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
   const bool use_wide = kind == KernelKind::Wide || (!is_super && fr.packed == nullptr);
   if (use_wide && fr.wide == nullptr) return hipErrorInvalidValue;
-  // the OH shape, and every wave gets more than one tile per launch: prefetch the next tile's fields
-  const bool pf = a.nfield == 27 && fr.num_feature == 27 && tune.launches_per_residency != 1 && tune.prefetch;
-#define OHX_LAUNCH_FIELDS(FMT, CH)                                                                                      \
-  return pf ? launch_fields_tiled(predict_fields_kernel<FMT, CH, true>, lds, fr, a, nrow, num_cus, stream, tune)         \
-            : launch_fields_tiled(predict_fields_kernel<FMT, CH, false>, lds, fr, a, nrow, num_cus, stream, tune)
+#define OHX_LAUNCH_FIELDS(FMT, CH) \
+  return launch_fields_tiled(predict_fields_kernel<FMT, CH>, lds, fr, a, nrow, num_cus, stream, tune)
   if (use_wide) OHX_LAUNCH_FIELDS(0, 1);
   switch (kind) {
     case KernelKind::Packed1: OHX_LAUNCH_FIELDS(1, 1);

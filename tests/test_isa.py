@@ -50,5 +50,5 @@ def test_default_walk_kernel_shape(isa):
 
 
 def test_fields_kernel_reads_its_table_from_lds_too(isa):
-    body = kernel_body(isa, "predict_fields_kernelILi2ELi2ELb1E")
+    body = kernel_body(isa, "predict_fields_kernelILi2ELi2E")
     assert body.count("ds_read_b128") >= 4
