@@ -9,10 +9,10 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/profile_$tag && mkdir -p $O && cd $R
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py > $O/bench_under_rocprof.log 2>&1
-tail -1 $O/bench_under_rocprof.log > $O/bench.json
+grep "^{\"metric\"" $O/bench_under_rocprof.log | tail -1 > $O/bench.json
 cp $O/trace/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 timeout -k 10 600 python3 bench.py > $O/bench_plain.log 2>&1
-tail -1 $O/bench_plain.log > $O/bench_plain.json
+grep "^{\"metric\"" $O/bench_plain.log | tail -1 > $O/bench_plain.json
 tools/pmc.sh $tag --no-verify > /dev/null 2>&1
 cp gpurun_out/pmc_$tag/summary.txt $O/pmc_summary.txt
 for c in FETCH_SIZE WRITE_SIZE; do
