@@ -519,7 +519,10 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
   const uint64_t nrow = plane * (uint64_t)(a.k2 - a.k1 + 1);
   const uint64_t slab = plane * (uint64_t)(a.k1 - a.src_k0);
   const uint64_t slab_out = plane * (uint64_t)(a.k1 - a.out_k0);
-  const uint64_t wave_id = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  // as in the rows kernel: blocks b and b + 8 share an XCD, give every XCD one contiguous run of tiles
+  uint32_t block = blockIdx.x;
+  if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint64_t wave_id = (uint64_t)block * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
   const float qnan = __builtin_nanf("");
   for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
@@ -1005,6 +1008,7 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
     a.shape.set_grid((uint32_t)a.im, (uint32_t)a.jm, 0, nrow, (uint32_t)tune.brick_li, (uint32_t)tune.brick_lj,
                      (uint32_t)tune.brick_lk);
   a.shape.k_fastest = (uint32_t)tune.brick_k_fastest;
+  a.xcd_remap = tune.xcd_remap;
   if (a.shape.ntiles(nrow) >= 0xFFFFFFFFull) a.shape = TileShape();
   const uint64_t ntiles = a.shape.ntiles(nrow);
   const int grid = tile_grid(kernel, lds, ntiles, num_cus);

@@ -132,6 +132,7 @@ struct FieldsArgs {
   float* margin_out = nullptr; // optional [N] raw margins in slab row order
   uint32_t* flags = nullptr;
   uint64_t tile_begin = 0, tile_end = 0;   // 64-row tiles of this launch
+  int xcd_remap = 1;           // give each XCD a contiguous range of tiles
   TileShape shape;             // lanes -> gridcells of the slab
 };
 

@@ -140,6 +140,16 @@ def test_gpu_kernels_on_random_boosters(ntree, nfeat, depth, p_leaf):
             b.set_param("ohx_kernel", kernel)
             got = b.predict(capi.DMatrix(rows, missing=missing))
             assert np.array_equal(helpers.bits(got), helpers.bits(want)), (kernel, missing)
+        # the clustering pass on trees of every shape (stumps, leaves at any depth, roots evaluated from the head or
+        # not): a key from the top of up to four trees, any number of steps - same margins
+        for trees, steps, z in ((1, 1, 0), (2, 7, 0), (4, 3, 1), (3, 16, 0)):
+            b = capi.Booster(model_buffer=js)
+            for k, v in (("ohx_cluster", "on"), ("ohx_cluster_trees", trees), ("ohx_cluster_steps", steps), ("ohx_cluster_zorder", z)):
+                b.set_param(k, v)
+            d = capi.DMatrix(rows, missing=missing)
+            d.set_grid(0, 0, 0)
+            got = b.predict(d)
+            assert np.array_equal(helpers.bits(got), helpers.bits(want)), ("cluster", trees, steps, missing)
     b = capi.Booster(model_buffer=js)
     leaves = b.predict(capi.DMatrix(rows, missing=-999.0), option_mask=16).reshape(len(rows), -1)
     assert np.array_equal(leaves, O.predict(model, rows, missing=-999.0, pred_leaf=True))
