@@ -532,21 +532,29 @@ const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a,
     b.d_cluster_keys[q].ensure(d.nrow);
     b.d_cluster_vals[q].ensure(d.nrow);
   }
-  b.d_cluster_small.ensure(1);
-  b.h_cluster_small.ensure(1);
+  b.d_cluster_small.ensure(9);
+  b.h_cluster_small.ensure(9);
   c.keys = b.d_cluster_keys[0].p;
   c.vals = b.d_cluster_vals[0].p;
   c.agree = b.d_cluster_small.p;
-  HIP_CHECK(hipMemsetAsync(c.agree, 0, sizeof(uint32_t), stream));
+  HIP_CHECK(hipMemsetAsync(c.agree, 0, 9 * sizeof(uint32_t), stream));
   HIP_CHECK(launch_cluster_keys(device_forest(b), c, b.dev.num_cus, stream));
   if (b.tune.cluster < 0 && !d.cluster_decided) {
-    HIP_CHECK(hipMemcpyAsync(b.h_cluster_small.p, c.agree, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(b.h_cluster_small.p, c.agree, 9 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    // observed agreement between neighbours in row order against what rows in random order would show
+    // (sum of squared shares of the eight outcomes): 0 = as good as shuffled, 1 = every row like the one before
+    const uint32_t* h = b.h_cluster_small.p;
+    const double n = (double)d.nrow, observed = (double)h[0] / n;
+    double by_chance = 0.0;
+    for (int v = 1; v <= 8; ++v) by_chance += ((double)h[v] / n) * ((double)h[v] / n);
+    const double order = by_chance < 0.999 ? (observed - by_chance) / (1.0 - by_chance) : 0.0;
     d.cluster_decided = true;
-    d.cluster_on = (double)b.h_cluster_small.p[0] < 0.5 * (double)d.nrow;
+    d.cluster_on = order < 0.33;
     if (getenv("OHX_DEBUG"))
-      fprintf(stderr, "[libohxgb] cluster verdict: %u of %llu rows agree with their predecessor on the first three decisions -> %s\n",
-              b.h_cluster_small.p[0], (unsigned long long)d.nrow, d.cluster_on ? "cluster" : "leave");
+      fprintf(stderr, "[libohxgb] cluster verdict: %.1f %% of the rows take the first three decisions of the row before them, "
+              "%.1f %% would by chance: order %.2f -> %s\n", 100.0 * observed, 100.0 * by_chance, order,
+              d.cluster_on ? "cluster" : "leave");
     if (!d.cluster_on) return nullptr;
   }
   size_t temp_bytes = 0;

@@ -618,8 +618,9 @@ __global__ __launch_bounds__(kBlock) void detect_period_kernel(const float* __re
 // whose super-nodes start below the root) and two decisions per super-node step, most significant first; a row
 // that reaches a leaf early keeps walking on fixed decisions.  zorder: the trees' decisions interleaved step by
 // step instead of tree after tree.  Also counts how many rows agree with the row before them on the first three
-// decisions of the first tree: rows in grid order mostly do (74 % on the C360 batch), shuffled rows mostly do
-// not (21 %).
+// decisions of the first tree - rows in grid order mostly do (74 % on the C360 batch), shuffled rows mostly do
+// not (21 %) - and how often each of the eight outcomes occurs, so that the host can tell "ordered" from "a
+// tree top that sends nearly every row the same way".
 constexpr int kKeyTileStride = kWave + 1;
 
 // NT = number of trees in the key (compile time: their walks are independent chains and must be in flight together)
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(kBlock) void cluster_keys_kernel(DeviceForest fr, C
   SuperTreeHead h[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) h[t] = fr.super_heads[t];
-  uint32_t agree = 0;
+  uint32_t agree = 0, seen = 0;
   for (uint64_t tile_id = (uint64_t)blockIdx.x * kWavesPerBlock + wave; tile_id < ntiles; tile_id += nwaves) {
     const uint64_t row = tile_id * kWave + lane;
     const bool valid = row < a.nrow;
@@ -735,9 +736,16 @@ __global__ __launch_bounds__(kBlock) void cluster_keys_kernel(DeviceForest fr, C
     const uint32_t prev = __shfl_up(lead, 1);
     const bool same = valid && lane != 0 && prev == lead;
     agree += __popcll(__ballot(same));
+    // how often each of the eight outcomes occurs at all: what two rows picked at random would agree on
+#pragma unroll
+    for (uint32_t v = 0; v < 8; ++v) {
+      const uint32_t n = (uint32_t)__popcll(__ballot(valid && (lead & 7u) == v));
+      if (lane == (int)v) seen += n;
+    }
     __builtin_amdgcn_wave_barrier();         // the next tile overwrites what this one's lanes were reading
   }
   if (lane == 0 && agree) atomicAdd(a.agree, agree);
+  if (lane < 8 && seen) atomicAdd(a.agree + 1 + lane, seen);
 }
 
 // ------------------------------------------------------------------ OH Run1: before and after the predict

@@ -185,7 +185,8 @@ struct ClusterArgs {
   uint32_t zorder = 0;               // interleave the trees' decisions step by step instead of tree after tree
   uint32_t* keys = nullptr;          // [nrow]
   uint32_t* vals = nullptr;          // [nrow] the row numbers 0 .. nrow-1, to be sorted along with the keys
-  uint32_t* agree = nullptr;         // one word, zero before: rows whose first three decisions equal the previous row's
+  uint32_t* agree = nullptr;         // nine words, zero before: [0] rows whose first three decisions (tree 0) equal the
+                                     // previous row's, [1..8] rows per outcome of those three decisions
 };
 uint32_t cluster_key_bits(const ClusterArgs& a);
 hipError_t launch_cluster_keys(const DeviceForest& forest, const ClusterArgs& a, int num_cus, hipStream_t stream);
