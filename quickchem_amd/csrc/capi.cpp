@@ -278,7 +278,7 @@ struct BoosterObj {
   DevBuf<SuperTreeHead> d_super_heads;
   bool super_ok = false;
   uint64_t super_slots = 0;
-  uint64_t super_gathers = 0;   // gathers a wave issues to walk the whole forest once (steps not served from LDS)
+  uint64_t super_gathers = 0;   // vector-memory instructions a wave issues to walk the whole forest once
   DevBuf<uint32_t> d_roots;
   DevBuf<uint32_t> d_flags;
   DevBuf<float> d_pred;
@@ -323,10 +323,11 @@ KernelKind pick_kernel(const BoosterObj& b) {
   return KernelKind::Packed2;
 }
 
-// Steps of every tree, less the first step of the trees whose start nodes sit in the kernels' LDS table
+// Vector-memory instructions a wave issues to walk the whole forest once (walk_super): per tree one coalesced
+// load of its top (steps 1-3) and one gather for every step after the third, of at least four steps
 uint64_t count_super_gathers(const SuperForest& sf) {
   uint64_t n = 0;
-  for (size_t t = 0; t < sf.heads.size(); ++t) n += sf.heads[t].steps - (t < kFirstStepTrees && sf.heads[t].steps ? 1u : 0u);
+  for (size_t t = 0; t < sf.heads.size(); ++t) n += (sf.heads[t].steps < 4u ? 4u : sf.heads[t].steps) - 2u;
   return n;
 }
 

@@ -221,6 +221,10 @@ bool emit_super(const Forest& f, SuperForest* out) {
         }
         s.meta = meta;
       }
+      // breadth first: the super-nodes of a walk's first three steps (levels 0-2: at most 2 + 8 + 32) and the
+      // fillers of group 0 lie in the tree's first kSuperTopSlots records - what walk_super's one coalesced
+      // "tree top" load per tree relies on
+      if (it.level <= 2 && it.slot >= kSuperTopSlots) throw OhxError("internal error: tree top outside its first records");
       sn[it.slot] = s;
       if (it.level + 1 > head.steps) head.steps = it.level + 1;
     }
@@ -228,6 +232,8 @@ bool emit_super(const Forest& f, SuperForest* out) {
     out->nodes.insert(out->nodes.end(), sn.begin(), sn.end());
     if (out->nodes.size() >= 0xFFFFFFF0ull) throw OhxError("booster too large for the super-node format");
   }
+  // the tree-top load of the last (small) tree reads kSuperTopSlots records from its base: keep that in bounds
+  out->nodes.insert(out->nodes.end(), kSuperTopSlots, unused);
   return true;
 }
 

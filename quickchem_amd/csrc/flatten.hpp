@@ -93,6 +93,10 @@ constexpr uint32_t super_meta(uint32_t f0, uint32_t fl, uint32_t fr, uint32_t dl
   return (fl & 31u) | (dl0 << 5) | (dll << 6) | (dlr << 7) | ((f0 & 31u) << 8) | ((fr & 31u) << 13) | (group << 18);
 }
 constexpr uint32_t kSuperMaxGroups = 1u << 14;
+// Groups are numbered breadth first, so the records a walk can stand on during its first three steps are among
+// the tree's first 48 (groups 0-11): the kernels fetch them with one coalesced load per tree and wave (one record
+// per lane) and hand them from lane to lane.  emit_super pads the array by this much behind the last tree.
+constexpr uint32_t kSuperTopSlots = 48;
 
 // Per tree: where the walk starts.  Phase-0 trees start at super-node base + 4.  Phase-1 trees
 // (super-nodes start at odd levels) evaluate the root from this record - it is the same for

@@ -301,11 +301,33 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
 constexpr uint32_t kFirstTrees = kFirstStepTrees;
 constexpr uint32_t kFirstBytes = kFirstTrees * 2 * 16;
 
+// Hands every lane the record that lane `rel` of the wave holds (rel < 64): four ds_bpermute_b32, which use the
+// LDS crossbar but neither LDS memory nor the texture addresser.
+template <int CHAINS>
+__device__ __forceinline__ void take_from_lanes(u32x4 (&s)[CHAINS], const u32x4 (&top)[CHAINS],
+                                                const uint32_t (&rel)[CHAINS]) {
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) {
+    const int a = (int)(rel[c] << 2);
+    s[c].x = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)top[c].x);
+    s[c].y = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)top[c].y);
+    s[c].z = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)top[c].z);
+    s[c].w = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)top[c].w);
+  }
+}
+
+// `tops`: fetch the first kSuperTopSlots records of each tree with ONE coalesced load per wave (a record per lane)
+// and take the super-nodes of steps 2 and 3 from the lane that holds them, instead of two gathers per lane:
+// a gather costs the texture addresser its fixed 16 cycles even when the whole wave wants the same two or
+// three records, as it does at the top of a tree.
 template <int CHAINS, bool HAS_MISSING>
 __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const SuperTreeHead* __restrict__ heads,
                                             uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile,
                                             const char* __restrict__ first, uint32_t nfirst) {
   if (t0 >= t1) return acc;
+  // lane l holds record min(l, kSuperTopSlots - 1) of the tree: the walk never asks for one beyond
+  const uint32_t lane_id = threadIdx.x & (kWave - 1);
+  const uint32_t top_off = (lane_id < kSuperTopSlots ? lane_id : kSuperTopSlots - 1u) << 4;
   const lds_cptr first_lds = (lds_cptr)first;
   const u32x4* __restrict__ nodes_v = reinterpret_cast<const u32x4*>(nodes);
   const char* tile_b = reinterpret_cast<const char*>(tile);
@@ -321,39 +343,52 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
       const uint32_t tn = t + CHAINS + c;
       hn[c] = heads[tn < t1 ? tn : t1 - 1];               // clamp: a duplicate walk is discarded below
     }
-    u32x4 s[CHAINS];
+    u32x4 s[CHAINS], top[CHAINS];
     // a lane's place in its tree: super-node index relative to the tree's first; the tree's own
     // address is wave-uniform, so a gather is base (SGPR pair) + 32-bit byte offset
     const char* tb[CHAINS];
     uint32_t rel[CHAINS], leafb[CHAINS];
     float xr[CHAINS];
+    // the trees' tops first: they are in flight during the root's compare and the first step
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) {
+      tb[c] = reinterpret_cast<const char*>(nodes_v + h[c].base);
+      top[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)top_off);
+    }
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) xr[c] = tile[(h[c].root_meta & 31u) * kWave];
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) {
       bool l = xr[c] < h[c].root_thr;
       if (HAS_MISSING) l = go_left_or_default(xr[c], h[c].root_thr, (h[c].root_meta & 32u) != 0u);
-      tb[c] = reinterpret_cast<const char*>(nodes_v + h[c].base);
       // group 1 holds the root's super-node (phase 0) or those of its two children (phase 1)
       rel[c] = 4u + (((h[c].root_meta & 0x100u) && !l) ? 1u : 0u);
       leafb[c] = 0u;
     }
     // The trip count is the tree's (a scalar from its head), not a vote of the lanes: no branch
-    // waits for the chains' compares, and the last step fetches nothing.
+    // waits for the chains' compares, and the last step fetches nothing.  Shallow trees take four
+    // steps as well: a walk that is past its leaf only meets fillers (flatten.hpp).
     uint32_t nsteps = h[0].steps;
 #pragma unroll
     for (int c = 1; c < CHAINS; ++c) nsteps = h[c].steps > nsteps ? h[c].steps : nsteps;
+    nsteps = nsteps < 4u ? 4u : nsteps;
     if (t + CHAINS <= nfirst) {
+      // step 1 from the block's LDS table: it does not wait for the tops
 #pragma unroll
       for (int c = 0; c < CHAINS; ++c) {
         const uint32_t tt = (t + c < t1) ? t + c : t1 - 1;
         s[c] = *(lds_u32x4_ptr)(first_lds + ((2u * tt + (rel[c] - 4u)) << 4));
       }
     } else {
-#pragma unroll
-      for (int c = 0; c < CHAINS; ++c) s[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)(rel[c] << 4));
+      take_from_lanes<CHAINS>(s, top, rel);
     }
-    for (uint32_t step = 1; step < nsteps; ++step) {
+    super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) asm volatile("" : "+v"(top[c]));   // one global_load_dwordx4 each
+    take_from_lanes<CHAINS>(s, top, rel);
+    super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+    take_from_lanes<CHAINS>(s, top, rel);
+    for (uint32_t step = 3; step < nsteps; ++step) {
       super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
 #pragma unroll
       for (int c = 0; c < CHAINS; ++c) s[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)(rel[c] << 4));
@@ -409,7 +444,7 @@ __device__ __forceinline__ uint32_t fill_first_steps(const DeviceForest& fr, con
 // AoS rows in, margins out.  PREFETCH27: 27-column rows, next tile's rows prefetched into
 // registers during the walk (used when a launch gives every wave more than one tile).
 template <int FMT, int CHAINS, bool PREFETCH27>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS > 5 ? 4 : 5))) void predict_rows_tile_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS > 4 ? 4 : 5))) void predict_rows_tile_kernel(
     DeviceForest fr, PredictArgs a, const SuperTreeHead* __restrict__ heads, float* __restrict__ out) {
   // `heads` (= fr.super_heads) and `out` (= a.out) are kernel arguments of their own so that they carry
   // noalias: with the margins' stores provably elsewhere, the wave-uniform head records stay scalar

@@ -112,7 +112,9 @@ struct LaunchTuning {
   uint64_t grid_row0 = 0;
   // log2 extents of a wave's brick; -1 = chosen per call (TileShape::set_grid_auto); all 0 = no bricks
   int brick_li = -1, brick_lj = -1, brick_lk = -1;
-  int brick_k_fastest = 0;
+  // lanes of a brick ordered level-fastest: the four lanes of a quad then share a column and with it the 2-D
+  // features, and ask the L1 for fewer distinct blocks (33.2 against 33.5 ms on the C360 step)
+  int brick_k_fastest = 1;
 };
 
 // 27 SoA fields of the MAPL state (OH_GridCompMod.F90:313-339), device pointers.

@@ -3,7 +3,9 @@ without a test noticing, and each costs measurable time on the MI355X (profiles/
   * the block's first-step table must be read with ds_read_b128; when hipcc loses the LDS address space of the
     pointer it emits flat_load_dwordx4 and every tree's first step goes through the texture addresser (+3.8 %);
   * no scratch (spills) and at most 84 VGPRs in the default kernel, or a CU holds fewer than 20 waves;
-  * super-nodes are fetched as ONE global_load_dwordx4 each (hipcc likes to split the vector, twice the gathers)."""
+  * super-nodes are fetched as ONE global_load_dwordx4 each (hipcc likes to split the vector, twice the gathers);
+  * steps 2 and 3 of a tree take their super-nodes from the lanes that hold the tree's top (ds_bpermute_b32), and
+    the top is one global_load_dwordx4 per tree, issued before the first step and not waited for until after it."""
 import os
 import re
 import shutil
@@ -44,6 +46,8 @@ def test_default_walk_kernel_shape(isa):
     body = kernel_body(isa, DEFAULT_KERNEL)
     assert body.count("ds_read_b128") >= 4                      # first-step table: two chains x with/without missing values
     assert body.count("global_load_dwordx4") >= 16
+    # two chains x two steps x four dwords, with and without missing values; a few more where a tree is beyond the table
+    assert body.count("ds_bpermute_b32") >= 32
     vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", body).group(1))
     assert vgpr <= 84, vgpr                                     # 6 waves per SIMD leave 85
     assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", body).group(1)) == 0

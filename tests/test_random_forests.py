@@ -75,7 +75,8 @@ def random_rows(rng, n, nfeat):
 
 
 CASES = [(1, 1, 0, 0.0), (3, 3, 1, 0.0), (7, 27, 6, 0.3), (40, 27, 12, 0.15), (5, 31, 9, 0.05), (9, 5, 30, 0.45),
-         (4, 32, 5, 0.2), (3, 40, 4, 0.2)]
+         (4, 32, 5, 0.2), (3, 40, 4, 0.2),
+         (150, 27, 7, 0.25)]   # more trees than the kernels' first-step table holds (128)
 
 
 @pytest.mark.parametrize("ntree,nfeat,depth,p_leaf", CASES)
