@@ -103,16 +103,6 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def kernel_symbol(kernel_arg, info, prefetch):
-    """The __global__ the selected configuration launches (csrc/kernels.hip launch_predict)."""
-    fmt = info["packed"]                          # 0 wide, 1 packed, 2 super-nodes: what the booster really uses
-    if kernel_arg == "wide" or fmt == 0:
-        return "predict_rows_direct_kernel<false>"
-    digits = "".join(ch for ch in kernel_arg if ch.isdigit())
-    chains = int(digits) if digits else 2
-    return f"predict_rows_tile_kernel<{fmt},{chains},{'true' if prefetch else 'false'}>"
-
-
 def fortran_cpu_leg(model_image, grid, fields, levels, threads, workdir):
     """oracle/lib/oh_mock_driver_oracle on the first `levels` levels of the batch's MAPL fields: the Fortran host's
     predict_OH_with_XGB (gather + XGDMatrixCreateFromMat + XGBoosterPredict + 10**) over the oracle library.
@@ -574,8 +564,6 @@ def main():
         cpu["margins_bit_identical_on_first_rows"] = n_chk
 
     if rank == 0:
-        lpr = [kv.partition("=")[2] for kv in args.param if kv.startswith("ohx_launches_per_residency=")]
-        prefetch = (lpr[-1] if lpr else "2") != "1" and "ohx_prefetch=0" not in args.param
         traffic, traffic_src = (None, "not the default single-GPU workload")
         if world == 1 and use_grid and plain and not args.param:
             traffic, traffic_src = measured_traffic(args.grid, args.kernel, info["num_nodes"])
@@ -600,7 +588,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "measured_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": kernel_symbol(args.kernel, info, prefetch), "kernel_ms": kernel_s * 1e3,
+                         "kernel": booster.kernel_symbol(27), "kernel_ms": kernel_s * 1e3,
                          "per": "step = the train of launches of one pass over the batch",
                          "launches_per_step": launches_per_step,
                          "avg_launch_us": kernel_s * 1e6 / launches_per_step,

@@ -250,8 +250,12 @@ int OHXSolarGeometryDevice(int jday, const float* d_lats, const float* d_lons, i
 /* Model facts for roofline accounting: info[0] trees, [1] nodes in the model,
  * [2] node slots in HBM, [3] bytes of the node array the selected kernel reads,
  * [4] max depth, [5] features, [6] node format in use (0 wide, 1 packed, 2 super-nodes),
- * [7] gather instructions one wavefront issues to walk the whole forest once (super-nodes). */
+ * [7] vector-memory instructions one wavefront issues to walk the whole forest once (super-nodes). */
 int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]);
+/* Name of the GPU kernel XGBoosterPredict / OHXBoosterPredictDevice launch for rows of `ncol` columns with the
+ * booster's current parameters, as a profiler prints it (without namespaces and arguments), e.g.
+ * "predict_rows_tile_kernel<2,2,true,true>".  *out stays valid until the next call on this handle. */
+int OHXBoosterKernelSymbol(BoosterHandle handle, bst_ulong ncol, const char** out);
 
 /* ------------------------------------------------------------------------
  * Part 4 — reassembling the OH field across the GPUs of a node (additive)

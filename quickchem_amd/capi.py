@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXDMatrixInferGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device", "OHXOHPostProcess", "OHXOHPostProcessDevice",
-    "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXReleaseScratch",
+    "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXBoosterKernelSymbol", "OHXReleaseScratch",
     "OHXCommGetUniqueId", "OHXCommInitRank", "OHXCommFree", "OHXShardRows", "OHXAllGatherOH",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
@@ -116,6 +116,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.OHXSolarGeometry.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp]
     lib.OHXSolarGeometryDevice.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp, vp]
     lib.OHXBoosterGetInfo.argtypes = [vp, C.POINTER(u64)]
+    lib.OHXBoosterKernelSymbol.argtypes = [vp, u64, C.POINTER(C.c_char_p)]
     lib.OHXReleaseScratch.argtypes = []
     lib.OHXCommGetUniqueId.argtypes = [vp]
     lib.OHXCommInitRank.argtypes = [vp, i32, i32, C.POINTER(vp)]
@@ -351,6 +352,11 @@ class Booster:
         keys = ["num_trees", "num_nodes", "num_slots", "node_bytes", "max_depth", "num_feature", "packed",
                 "gathers_per_wave"]
         return {k: int(arr[i]) for i, k in enumerate(keys)}
+
+    def kernel_symbol(self, ncol: int) -> str:
+        out = C.c_char_p()
+        check(self.lib, self.lib.OHXBoosterKernelSymbol(self.handle, ncol, C.byref(out)))
+        return out.value.decode()
 
     def free(self) -> None:
         if self.handle:

@@ -278,7 +278,10 @@ struct BoosterObj {
   DevBuf<SuperTreeHead> d_super_heads;
   bool super_ok = false;
   uint64_t super_slots = 0;
-  uint64_t super_gathers = 0;   // vector-memory instructions a wave issues to walk the whole forest once
+  uint64_t super_gathers[2] = {0, 0};   // vector-memory instructions a wave issues to walk the whole forest once
+                                        // without / with tree tops
+  double super_mean_steps = 0.0;
+  std::string symbol;                   // OHXBoosterKernelSymbol's answer
   DevBuf<uint32_t> d_roots;
   DevBuf<uint32_t> d_flags;
   DevBuf<float> d_pred;
@@ -313,8 +316,6 @@ KernelKind pick_kernel(const BoosterObj& b) {
     if (k == "super1") return KernelKind::Super1;
     if (k == "super3") return KernelKind::Super3;
     if (k == "super4") return KernelKind::Super4;
-    if (k == "super5") return KernelKind::Super5;
-    if (k == "super6") return KernelKind::Super6;
     if (k == "super2" || k == "auto") return KernelKind::Super2;
   }
   if (!b.packed_ok) return KernelKind::Wide;
@@ -323,12 +324,30 @@ KernelKind pick_kernel(const BoosterObj& b) {
   return KernelKind::Packed2;
 }
 
-// Vector-memory instructions a wave issues to walk the whole forest once (walk_super): per tree one coalesced
-// load of its top (steps 1-3) and one gather for every step after the third, of at least four steps
-uint64_t count_super_gathers(const SuperForest& sf) {
+// Vector-memory instructions a wave issues to walk the whole forest once (walk_super).  With tree tops: per tree
+// one coalesced load of its top (steps 1-3) and one gather for every step after the third, of at least four
+// steps.  Without: a gather per step, less the first step of the trees whose start nodes sit in the kernels'
+// LDS table.
+uint64_t count_super_gathers(const SuperForest& sf, bool tops) {
   uint64_t n = 0;
-  for (size_t t = 0; t < sf.heads.size(); ++t) n += (sf.heads[t].steps < 4u ? 4u : sf.heads[t].steps) - 2u;
+  for (size_t t = 0; t < sf.heads.size(); ++t) {
+    const uint32_t steps = sf.heads[t].steps;
+    n += tops ? (steps < 4u ? 4u : steps) - 2u : steps - (t < kFirstStepTrees && steps ? 1u : 0u);
+  }
   return n;
+}
+
+// Tree tops pay where the texture addresser is the bound: deep trees.  Measured on the MI355X with the OH
+// recipe's boosters (profiles/r02_sweeps.txt): 9 steps per tree (depth 18) 3.4 % faster with, 5 steps (depth 10)
+// 10 % slower, 3 steps (depth 6) 27 % slower.
+constexpr double kTreeTopsMinMeanSteps = 7.0;
+double mean_super_steps(const SuperForest& sf) {
+  double n = 0;
+  for (const SuperTreeHead& h : sf.heads) n += h.steps;
+  return sf.heads.empty() ? 0.0 : n / (double)sf.heads.size();
+}
+bool use_tree_tops(const LaunchTuning& tune, double mean_steps) {
+  return tune.tree_tops < 0 ? mean_steps >= kTreeTopsMinMeanSteps : tune.tree_tops != 0;
 }
 
 bool wants_super(const std::string& k) { return k == "auto" || (k.size() == 6 && k.compare(0, 5, "super") == 0); }
@@ -364,7 +383,9 @@ void ensure_uploaded(BoosterObj& b) {
     b.super_ok = emit_super(b.forest, &sf) && sf.nodes.size() * sizeof(SuperNode) < 0xFFFFFFF0ull;
     if (b.super_ok) {
       b.super_slots = sf.nodes.size();
-      b.super_gathers = count_super_gathers(sf);
+      b.super_gathers[0] = count_super_gathers(sf, false);
+      b.super_gathers[1] = count_super_gathers(sf, true);
+      b.super_mean_steps = mean_super_steps(sf);
       b.d_super.upload(sf.nodes);
       b.d_super_heads.upload(sf.heads);
     }
@@ -391,6 +412,7 @@ DeviceForest device_forest(const BoosterObj& b) {
   d.num_trees = (uint32_t)b.forest.trees.size();
   d.num_feature = b.forest.num_feature;
   d.base_score = b.margin_base;
+  d.tree_tops = (b.super_ok && use_tree_tops(b.tune, b.super_mean_steps)) ? 1u : 0u;
   return d;
 }
 
@@ -846,8 +868,8 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
   const std::string n(name), v(value);
   if (n == "ohx_kernel") {
     if (v != "auto" && v != "wide" && v != "packed1" && v != "packed2" && v != "packed4" && v != "super1" &&
-        v != "super2" && v != "super3" && v != "super4" && v != "super5" && v != "super6")
-      throw OhxError("ohx_kernel must be one of auto, wide, packed1, packed2, packed4, super1 .. super6");
+        v != "super2" && v != "super3" && v != "super4")
+      throw OhxError("ohx_kernel must be one of auto, wide, packed1, packed2, packed4, super1 .. super4");
     if (v != b->kernel_name) invalidate_device_state(*b);
     b->kernel_name = v;
   } else if (n == "ohx_top_levels") {
@@ -909,6 +931,10 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     b->tune.prefetch = atoi(value) != 0;
   } else if (n == "ohx_xcd_remap") {
     b->tune.xcd_remap = atoi(value) != 0;
+  } else if (n == "ohx_tree_tops") {
+    const std::string v = value;
+    if (v != "auto" && v != "on" && v != "off") throw OhxError("ohx_tree_tops must be auto, on or off");
+    b->tune.tree_tops = v == "auto" ? -1 : (v == "on" ? 1 : 0);
   } else if (n == "ohx_device") {
     int k = atoi(value);
     if (k != b->device_pref) invalidate_device_state(*b);
@@ -1383,7 +1409,8 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
   }
   const bool packed_used = packed_ok && b->kernel_name != "wide";
   bool super_used = false;
-  uint64_t super_slots = b->super_slots, super_gathers = b->super_gathers;
+  uint64_t super_slots = b->super_slots;
+  uint64_t super_gathers = b->super_gathers[use_tree_tops(b->tune, b->super_mean_steps) ? 1 : 0];
   if (wants_super(b->kernel_name)) {
     if (b->uploaded) {
       super_used = b->super_ok;
@@ -1391,7 +1418,7 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
       SuperForest sf;
       super_used = emit_super(b->forest, &sf);
       super_slots = sf.nodes.size();
-      super_gathers = count_super_gathers(sf);
+      super_gathers = count_super_gathers(sf, use_tree_tops(b->tune, mean_super_steps(sf)));
     }
   }
   info[0] = b->forest.trees.size();
@@ -1403,6 +1430,16 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
   info[5] = b->forest.num_feature;
   info[6] = super_used ? 2 : (packed_used ? 1 : 0);
   info[7] = super_used ? super_gathers : 0;
+  API_END();
+}
+
+int OHXBoosterKernelSymbol(BoosterHandle handle, bst_ulong ncol, const char** out) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (out == nullptr) throw OhxError("OHXBoosterKernelSymbol: out is NULL");
+  ensure_uploaded(*b);
+  b->symbol = predict_kernel_symbol(pick_kernel(*b), device_forest(*b), (uint32_t)ncol, b->tune);
+  *out = b->symbol.c_str();
   API_END();
 }
 

@@ -316,11 +316,15 @@ __device__ __forceinline__ void take_from_lanes(u32x4 (&s)[CHAINS], const u32x4 
   }
 }
 
-// `tops`: fetch the first kSuperTopSlots records of each tree with ONE coalesced load per wave (a record per lane)
-// and take the super-nodes of steps 2 and 3 from the lane that holds them, instead of two gathers per lane:
-// a gather costs the texture addresser its fixed 16 cycles even when the whole wave wants the same two or
-// three records, as it does at the top of a tree.
-template <int CHAINS, bool HAS_MISSING>
+// TOPS: fetch the first kSuperTopSlots records of each tree with ONE coalesced load per wave (a record per lane)
+// and take the super-nodes of steps 2 and 3 from the lane that holds them, instead of two gathers per lane.
+// A gather costs the texture addresser its fixed 16 cycles even when the whole wave wants the same two or
+// three records, as it does at the top of a tree.  It pays where the addresser is the bound -
+// deep trees, whose lower steps keep it busy (C360 step, depth 18: 34.5 -> 33.4 ms) - and costs where it is not:
+// the load brings twelve 64-byte lines where the two gathers touch two to four, and the eight ds_bpermute per
+// chain are work the shallow walk has no slack for (depth 6: 11.5 -> 14.6 ms, depth 10: 16.5 -> 18.3 ms).  The
+// host picks the kernel by the forest's mean step count (capi.cpp device_forest).
+template <int CHAINS, bool HAS_MISSING, bool TOPS>
 __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const SuperTreeHead* __restrict__ heads,
                                             uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile,
                                             const char* __restrict__ first, uint32_t nfirst) {
@@ -353,7 +357,7 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) {
       tb[c] = reinterpret_cast<const char*>(nodes_v + h[c].base);
-      top[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)top_off);
+      if (TOPS) top[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)top_off);
     }
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) xr[c] = tile[(h[c].root_meta & 31u) * kWave];
@@ -366,12 +370,11 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
       leafb[c] = 0u;
     }
     // The trip count is the tree's (a scalar from its head), not a vote of the lanes: no branch
-    // waits for the chains' compares, and the last step fetches nothing.  Shallow trees take four
-    // steps as well: a walk that is past its leaf only meets fillers (flatten.hpp).
+    // waits for the chains' compares, and the last step fetches nothing.  The shallower tree of a group
+    // walks on through fillers (flatten.hpp).
     uint32_t nsteps = h[0].steps;
 #pragma unroll
     for (int c = 1; c < CHAINS; ++c) nsteps = h[c].steps > nsteps ? h[c].steps : nsteps;
-    nsteps = nsteps < 4u ? 4u : nsteps;
     if (t + CHAINS <= nfirst) {
       // step 1 from the block's LDS table: it does not wait for the tops
 #pragma unroll
@@ -379,19 +382,32 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
         const uint32_t tt = (t + c < t1) ? t + c : t1 - 1;
         s[c] = *(lds_u32x4_ptr)(first_lds + ((2u * tt + (rel[c] - 4u)) << 4));
       }
-    } else {
+    } else if (TOPS) {
       take_from_lanes<CHAINS>(s, top, rel);
-    }
-    super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
-#pragma unroll
-    for (int c = 0; c < CHAINS; ++c) asm volatile("" : "+v"(top[c]));   // one global_load_dwordx4 each
-    take_from_lanes<CHAINS>(s, top, rel);
-    super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
-    take_from_lanes<CHAINS>(s, top, rel);
-    for (uint32_t step = 3; step < nsteps; ++step) {
-      super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+    } else {
 #pragma unroll
       for (int c = 0; c < CHAINS; ++c) s[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)(rel[c] << 4));
+    }
+    if (TOPS) {
+      // a shallow tree in a deep forest takes four steps as well: past its leaf a walk only meets fillers
+      nsteps = nsteps < 4u ? 4u : nsteps;
+      super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) asm volatile("" : "+v"(top[c]));   // one global_load_dwordx4 each
+      take_from_lanes<CHAINS>(s, top, rel);
+      super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+      take_from_lanes<CHAINS>(s, top, rel);
+      for (uint32_t step = 3; step < nsteps; ++step) {
+        super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) s[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)(rel[c] << 4));
+      }
+    } else {
+      for (uint32_t step = 1; step < nsteps; ++step) {
+        super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) s[c] = *reinterpret_cast<const u32x4*>(tb[c] + (uint64_t)(rel[c] << 4));
+      }
     }
     super_step<CHAINS, HAS_MISSING, true>(s, rel, leafb, tile_b);
 #pragma unroll
@@ -402,7 +418,7 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 }
 
 // FMT: 0 = wide 16-byte nodes, 1 = packed 8-byte nodes, 2 = 16-byte super-nodes
-template <int FMT, int CHAINS>
+template <int FMT, int CHAINS, bool TOPS>
 __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads, uint32_t t0,
                                            uint32_t t1, const float* tile, bool wave_has_missing, const char* first,
                                            uint32_t nfirst) {
@@ -414,8 +430,8 @@ __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTr
   } else if constexpr (FMT == 2) {
     // plain 128-bit global loads: measured 8 % faster than buffer loads on the divergent deep levels
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.super);
-    return wave_has_missing ? walk_super<CHAINS, true>(nodes, heads, t0, t1, acc, tile, first, nfirst)
-                            : walk_super<CHAINS, false>(nodes, heads, t0, t1, acc, tile, first, nfirst);
+    return wave_has_missing ? walk_super<CHAINS, true, TOPS>(nodes, heads, t0, t1, acc, tile, first, nfirst)
+                            : walk_super<CHAINS, false, TOPS>(nodes, heads, t0, t1, acc, tile, first, nfirst);
   } else {
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
     return wave_has_missing ? walk_wide_tile<true>(nodes, fr.roots, t0, t1, acc, tile)
@@ -443,8 +459,8 @@ __device__ __forceinline__ uint32_t fill_first_steps(const DeviceForest& fr, con
 
 // AoS rows in, margins out.  PREFETCH27: 27-column rows, next tile's rows prefetched into
 // registers during the walk (used when a launch gives every wave more than one tile).
-template <int FMT, int CHAINS, bool PREFETCH27>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS > 4 ? 4 : 5))) void predict_rows_tile_kernel(
+template <int FMT, int CHAINS, bool PREFETCH27, bool TOPS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS > 3 ? 4 : 5))) void predict_rows_tile_kernel(
     DeviceForest fr, PredictArgs a, const SuperTreeHead* __restrict__ heads, float* __restrict__ out) {
   // `heads` (= fr.super_heads) and `out` (= a.out) are kernel arguments of their own so that they carry
   // noalias: with the margins' stores provably elsewhere, the wave-uniform head records stay scalar
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
         load_row27(regs, a.rows, valid ? row : 0);   // in flight during the walk
       }
       const bool wave_nan = __any(lane_nan);
-      const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
+      const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
       if (this_valid) __builtin_nontemporal_store(acc, out + this_row);
       tile_id = next;
     }
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
                                          missing_is_nan, a.flags);
     const bool wave_nan = __any(lane_nan);
     // the tile is private to this wave: its own LDS writes are ordered before its reads
-    const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
+    const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
     if (valid) __builtin_nontemporal_store(acc, out + row);
   }
 }
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void predict_rows_direct_kernel(DeviceFores
 // The fused path: reads the MAPL fields in place (lane = consecutive i, coalesced),
 // applies PL/100 (OH_GridCompMod.F90:314), walks, writes 10**pred * OHscale
 // (OH_GridCompMod.F90:369,1569) into OH_ML(i,j,k1..k2).
-template <int FMT, int CHAINS>
+template <int FMT, int CHAINS, bool TOPS>
 __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr, FieldsArgs a, const SuperTreeHead* __restrict__ heads,
                                                                 float* __restrict__ out,
                                                                 float* __restrict__ margin_out) {
@@ -580,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
     }
     if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
     const bool wave_nan = __any(lane_nan);
-    const float acc = walk_tile<FMT, CHAINS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
+    const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
     if (valid) {
       if (margin_out) margin_out[m] = acc;
       float oh = acc;
@@ -999,8 +1015,6 @@ const char* kernel_kind_name(KernelKind k) {
     case KernelKind::Super2: return "super2";
     case KernelKind::Super3: return "super3";
     case KernelKind::Super4: return "super4";
-    case KernelKind::Super5: return "super5";
-    case KernelKind::Super6: return "super6";
   }
   return "?";
 }
@@ -1009,7 +1023,7 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
                           hipStream_t stream, const LaunchTuning& tune) {
   if (a.nrow == 0) return hipSuccess;
   const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
-                        kind == KernelKind::Super4 || kind == KernelKind::Super5 || kind == KernelKind::Super6;
+                        kind == KernelKind::Super4;
   const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
   const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && a.ncol <= fr.num_feature;
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
@@ -1022,21 +1036,38 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
   }
   // every wave gets more than one tile per launch and the rows are the OH shape: prefetch
   const bool pf = a.ncol == 27 && fr.num_feature == 27 && tune.launches_per_residency != 1 && tune.prefetch;
-#define OHX_ROWS(FMT, CH)                                                                                    \
-  return pf ? launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, true>, lds, fr, a, num_cus, stream, tune)   \
-            : launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, false>, lds, fr, a, num_cus, stream, tune)
+#define OHX_ROWS_T(FMT, CH, TOPS)                                                                                  \
+  return pf ? launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, true, TOPS>, lds, fr, a, num_cus, stream, tune)   \
+            : launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, false, TOPS>, lds, fr, a, num_cus, stream, tune)
+#define OHX_ROWS(FMT, CH)                    \
+  if (fr.tree_tops) OHX_ROWS_T(FMT, CH, true); \
+  OHX_ROWS_T(FMT, CH, false)
   switch (kind) {
-    case KernelKind::Packed1: OHX_ROWS(1, 1);
-    case KernelKind::Packed2: OHX_ROWS(1, 2);
-    case KernelKind::Packed4: OHX_ROWS(1, 4);
+    case KernelKind::Packed1: OHX_ROWS_T(1, 1, false);
+    case KernelKind::Packed2: OHX_ROWS_T(1, 2, false);
+    case KernelKind::Packed4: OHX_ROWS_T(1, 4, false);
     case KernelKind::Super1: OHX_ROWS(2, 1);
     case KernelKind::Super3: OHX_ROWS(2, 3);
     case KernelKind::Super4: OHX_ROWS(2, 4);
-    case KernelKind::Super5: OHX_ROWS(2, 5);
-    case KernelKind::Super6: OHX_ROWS(2, 6);
     default: OHX_ROWS(2, 2);
   }
 #undef OHX_ROWS
+#undef OHX_ROWS_T
+}
+
+std::string predict_kernel_symbol(KernelKind kind, const DeviceForest& fr, uint32_t ncol, const LaunchTuning& tune) {
+  const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
+                        kind == KernelKind::Super4;
+  const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
+  const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && ncol <= fr.num_feature;
+  if (kind == KernelKind::Wide || !tile_ok || (!is_super && fr.packed == nullptr)) return "predict_rows_direct_kernel<false>";
+  const bool pf = ncol == 27 && fr.num_feature == 27 && tune.launches_per_residency != 1 && tune.prefetch;
+  int chains = 2;
+  if (kind == KernelKind::Packed1 || kind == KernelKind::Super1) chains = 1;
+  if (kind == KernelKind::Super3) chains = 3;
+  if (kind == KernelKind::Packed4 || kind == KernelKind::Super4) chains = 4;
+  return std::string("predict_rows_tile_kernel<") + (is_super ? "2," : "1,") + std::to_string(chains) +
+         (pf ? ",true," : ",false,") + (is_super && fr.tree_tops ? "true>" : "false>");
 }
 
 // Same train of launches as the row kernels: a launch per `launches_per_residency` residencies
@@ -1073,27 +1104,29 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   if (a.k2 < a.k1 || a.im <= 0 || a.jm <= 0) return hipSuccess;
   const uint64_t nrow = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)(a.k2 - a.k1 + 1);
   const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
-                        kind == KernelKind::Super4 || kind == KernelKind::Super5 || kind == KernelKind::Super6;
+                        kind == KernelKind::Super4;
   const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
   if (fr.num_feature < 1 || lds > 160 * 1024) return hipErrorInvalidValue;
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
   const bool use_wide = kind == KernelKind::Wide || (!is_super && fr.packed == nullptr);
   if (use_wide && fr.wide == nullptr) return hipErrorInvalidValue;
-#define OHX_LAUNCH_FIELDS(FMT, CH) \
-  return launch_fields_tiled(predict_fields_kernel<FMT, CH>, lds, fr, a, nrow, num_cus, stream, tune)
-  if (use_wide) OHX_LAUNCH_FIELDS(0, 1);
+#define OHX_LAUNCH_FIELDS_T(FMT, CH, TOPS) \
+  return launch_fields_tiled(predict_fields_kernel<FMT, CH, TOPS>, lds, fr, a, nrow, num_cus, stream, tune)
+#define OHX_LAUNCH_FIELDS(FMT, CH)                    \
+  if (fr.tree_tops) OHX_LAUNCH_FIELDS_T(FMT, CH, true); \
+  OHX_LAUNCH_FIELDS_T(FMT, CH, false)
+  if (use_wide) OHX_LAUNCH_FIELDS_T(0, 1, false);
   switch (kind) {
-    case KernelKind::Packed1: OHX_LAUNCH_FIELDS(1, 1);
-    case KernelKind::Packed2: OHX_LAUNCH_FIELDS(1, 2);
-    case KernelKind::Packed4: OHX_LAUNCH_FIELDS(1, 4);
+    case KernelKind::Packed1: OHX_LAUNCH_FIELDS_T(1, 1, false);
+    case KernelKind::Packed2: OHX_LAUNCH_FIELDS_T(1, 2, false);
+    case KernelKind::Packed4: OHX_LAUNCH_FIELDS_T(1, 4, false);
     case KernelKind::Super1: OHX_LAUNCH_FIELDS(2, 1);
     case KernelKind::Super3: OHX_LAUNCH_FIELDS(2, 3);
     case KernelKind::Super4: OHX_LAUNCH_FIELDS(2, 4);
-    case KernelKind::Super5: OHX_LAUNCH_FIELDS(2, 5);
-    case KernelKind::Super6: OHX_LAUNCH_FIELDS(2, 6);
     default: OHX_LAUNCH_FIELDS(2, 2);
   }
 #undef OHX_LAUNCH_FIELDS
+#undef OHX_LAUNCH_FIELDS_T
 }
 
 uint32_t cluster_key_bits(const ClusterArgs& a) { return a.ntrees * (1u + 2u * a.nsteps); }

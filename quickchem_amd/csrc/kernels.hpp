@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <string>
 
 #include "flatten.hpp"
 
@@ -30,6 +31,8 @@ struct DeviceForest {
   // descriptors, whose range check also turns any stray index into a harmless zero read)
   uint32_t packed_bytes = 0;
   uint32_t super_bytes = 0;
+  // super-nodes: walk with one coalesced "tree top" load per tree (kernels.hip walk_super); chosen by the host
+  uint32_t tree_tops = 0;
 };
 
 // Which 64 rows a wave takes.  Without a grid (im == 0) tile t is rows 64t .. 64t+63.  With the
@@ -101,6 +104,8 @@ struct LaunchTuning {
   // an XCD walk the same few trees at the same time and share their node lines in that XCD's L2.
   int launches_per_residency = 2;
   int xcd_remap = 1;
+  // tree tops (walk_super): -1 = by the forest's mean step count (deep forests), 0 = never, 1 = always
+  int tree_tops = -1;
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
   // rows in no known order: -1 = decide per matrix (cluster unless the rows look ordered), 0 = never, 1 = always
@@ -197,9 +202,11 @@ hipError_t launch_cluster_keys(const DeviceForest& forest, const ClusterArgs& a,
 hipError_t sort_pairs_u32(void* temp, size_t* temp_bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
                           uint32_t* vals_b, uint64_t n, unsigned key_bits, hipStream_t stream, uint32_t** sorted_vals);
 
-enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super3, Super4, Super5, Super6 };
+enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super3, Super4 };
 
 const char* kernel_kind_name(KernelKind k);
+// the __global__ launch_predict would launch for rows of `ncol` columns (for profiles and bench.py)
+std::string predict_kernel_symbol(KernelKind kind, const DeviceForest& forest, uint32_t ncol, const LaunchTuning& tune);
 
 hipError_t launch_predict(KernelKind kind, const DeviceForest& forest, const PredictArgs& a, int num_cus,
                           hipStream_t stream, const LaunchTuning& tune = LaunchTuning());

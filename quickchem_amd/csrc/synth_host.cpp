@@ -297,9 +297,10 @@ int ohx_super_walk_cpu(const uint8_t* model, uint64_t model_len, const float* ro
         uint32_t rel = 4u;
         if (h.root_meta & 0x100u) rel += left(x[h.root_meta & 31u], h.root_thr, (h.root_meta & 32u) != 0) ? 0u : 1u;
         uint32_t leaf_bits = 0;
-        // as walk_super does: never fewer than four steps (a walk past its leaf only meets fillers), and
-        // the records of the first three steps among the tree's first kSuperTopSlots (its one "top" load)
-        const uint32_t nsteps = h.steps < 4u ? 4u : h.steps;
+        // as walk_super does: the records of the first three steps among the tree's first kSuperTopSlots
+        // (its one "top" load); two more steps than the tree has, as when it shares a group of chains with a
+        // deeper tree (a walk past its leaf only meets fillers)
+        const uint32_t nsteps = h.steps + 2u;
         for (uint32_t step = 0; step < nsteps; ++step) {
           if (step < 3 && rel >= kSuperTopSlots) throw OhxError("tree top outside the first records of its tree");
           if ((size_t)h.base + rel >= sf.nodes.size()) throw OhxError("walk left the super-node array");

@@ -14,7 +14,7 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["wide", "packed1", "packed2", "packed4", "super1", "super2", "super3", "super4", "super6"]
+KERNELS = ["wide", "packed1", "packed2", "packed4", "super1", "super2", "super3", "super4"]
 
 
 @pytest.fixture(scope="module")
@@ -503,3 +503,31 @@ def test_rows_in_no_order_are_grouped_before_the_walk(torch_cuda, small_model, d
     d = capi.DMatrix(narrow, missing=float("nan"))
     assert np.array_equal(helpers.bits(b.predict(d)), helpers.bits(helpers.oracle_predict(small_model.image, narrow, float("nan"))))
     d.free()
+
+
+@pytest.mark.parametrize("tops", ["on", "off", "auto"])
+def test_tree_tops_walk_gives_the_same_margins(torch_cuda, small_model, deep_model, tops):
+    """walk_super with and without the coalesced tree-top load (ohx_tree_tops): same margins on deep and shallow
+    boosters, with missing values, with more trees than the first-step table holds; `auto` picks it for the deep
+    booster (9 steps per tree) and not for the shallow one (5), and the library names the kernel it launches."""
+    rows = with_missing(synth.rows_cpu(synth.GRIDS["C12"], 0, 12 * 72 * 30), 0.01)
+    hand = open(os.path.join(helpers.GOLDEN, "hand_forest.json"), "rb").read()
+    many = synth.make_model(num_trees=150, max_depth=5, sample_log2=12, min_leaf=2, grid=synth.GRIDS["C12"])
+    for image, deep in ((small_model.image, False), (deep_model.image, True), (many.image, False), (hand, False)):
+        if image is hand:
+            cases, x = helpers.load_hand_cases()
+            miss, want = cases["missing"], np.float32(cases["margin"])      # the golden vector
+        else:
+            x, miss = rows, synth.XX_MISS
+            want = helpers.oracle_predict(image, x, miss)
+        for kernel in ("super2", "super3"):
+            got = gpu_predict(image, x, miss, kernel, params={"ohx_tree_tops": tops})
+            assert np.array_equal(helpers.bits(got), helpers.bits(want)), (kernel, tops, deep)
+        b = capi.Booster(model_buffer=image)
+        b.set_param("ohx_tree_tops", tops)
+        sym = b.kernel_symbol(x.shape[1])
+        uses = {"on": True, "off": False, "auto": deep}[tops]
+        assert sym.startswith("predict_rows_tile_kernel<2,2,") and sym.endswith(",true>" if uses else ",false>"), sym
+        b.free()
+    with pytest.raises(capi.OhxError, match="ohx_tree_tops"):
+        capi.Booster(model_buffer=hand).set_param("ohx_tree_tops", "maybe")

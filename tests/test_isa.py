@@ -16,7 +16,7 @@ import pytest
 from tests import helpers
 
 HIPCC = "/opt/rocm/bin/hipcc"
-DEFAULT_KERNEL = "predict_rows_tile_kernelILi2ELi2ELb1E"
+DEFAULT_KERNEL = "predict_rows_tile_kernelILi2ELi2ELb1ELb1E"      # <super-nodes, 2 chains, prefetch, tree tops>
 
 
 @pytest.fixture(scope="module")
@@ -54,5 +54,5 @@ def test_default_walk_kernel_shape(isa):
 
 
 def test_fields_kernel_reads_its_table_from_lds_too(isa):
-    body = kernel_body(isa, "predict_fields_kernelILi2ELi2E")
+    body = kernel_body(isa, "predict_fields_kernelILi2ELi2ELb1E")
     assert body.count("ds_read_b128") >= 4

@@ -13,7 +13,11 @@ import json, sys
 v, line = sys.argv[1], sys.argv[2]
 try:
     d = json.loads(line)
-    print(f"{d['value']/1e6:9.1f} Mcells/s  kernel {d['roofline']['kernel_ms']:8.2f} ms  frac {d['roofline']['frac']:.4f}  | {v}")
+    r = d.get('roofline') or {}
+    if 'kernel_ms' in r:
+        print(f"{d['value']/1e6:9.1f} Mcells/s  kernel {r['kernel_ms']:8.2f} ms  frac {r['frac']:.4f}  | {v}")
+    else:
+        print(f"{d['value']/1e6:9.1f} Mcells/s  step   {d['ms_per_step']:8.2f} ms               | {v}")
 except Exception as e:
     print(f"FAILED | {v} | {line[:200]}")
 PY
