@@ -310,7 +310,8 @@ def measured_traffic(grid_name, kernel, model_nodes):
         if t.get("workload") != grid_name or t.get("model_nodes") != model_nodes or kernel not in ("auto", t.get("kernel")):
             continue
         if t.get("kernel_source_hash") != have:
-            why = f"profiles/{name} was measured on other kernel sources ({t.get('kernel_source_hash')} != {have})"
+            if not why.startswith("profiles/"):       # name the newest such file, not the oldest
+                why = f"profiles/{name} was measured on other kernel sources ({t.get('kernel_source_hash')} != {have})"
             continue
         return t.get("traffic_bytes_per_step"), f"profiles/{name}"
     return None, why
