@@ -93,11 +93,19 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
                      bst_ulong* out_len, const float** out_result);
 
 /* xgboost c_api.h; not bound by the reference.  Understood names:
- *   "ohx_kernel"      auto (= super2) | super1 | super2 | super4 | packed1 | packed2 |
+ *   "ohx_kernel"      auto (= super2) | super1 | super2 | super3 | super4 | packed1 | packed2 |
  *                     packed4 | wide : node format and trees in flight per lane
+ *   "ohx_tree_tops"   auto | on | off : super-nodes: fetch a tree's first records with one coalesced load per
+ *                     wavefront (auto = forests of 7 or more steps per tree, where it is faster)
+ *   "ohx_cluster"     auto | on | off : group rows of no known order by the decisions they take at the top of
+ *                     the first trees before walking them ("ohx_cluster_trees", "ohx_cluster_steps",
+ *                     "ohx_cluster_zorder" shape the key)
  *   "ohx_launches_per_residency"  tiles per wave per launch (default 2; 0 = one launch)
+ *   "ohx_brick" = "a,b,c", "ohx_brick_k_fastest", "ohx_prefetch", "ohx_xcd_remap", "ohx_lds_pad"
+ *                     launch-shape knobs behind profiles/ *_sweeps.txt; the defaults are the measured best
  *   "ohx_top_levels", "ohx_line_slots", "ohx_min_chunk"  placement of the packed format
  *   "ohx_device"      HIP device ordinal for this booster
+ * None of them changes a prediction.
  * xgboost's own parameter names ("nthread", "predictor", ...) are accepted and
  * ignored. */
 int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value);
