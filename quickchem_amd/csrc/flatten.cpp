@@ -1,5 +1,7 @@
 #include "flatten.hpp"
 
+#include <limits>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -160,7 +162,11 @@ bool emit_super(const Forest& f, SuperForest* out) {
   out->nodes.clear();
   out->heads.clear();
   if (f.num_feature > kSuperLeaf) return false;
-  const SuperNode unused{0.0f, 0.0f, 0.0f, super_meta(kSuperLeaf, kSuperLeaf, kSuperLeaf, 0, 0, 0, 0)};
+  // a filler looks like an internal node that sends everything - numbers below its +inf thresholds, NaN by its
+  // default-left bits - to slot 0 of group 0, i.e. to a filler; none of its codes says "leaf" (flatten.hpp)
+  const float inf = std::numeric_limits<float>::infinity();
+  const SuperNode unused{inf, inf, inf, super_meta(0, 0, 0, 1, 1, 1, 0)};
+  const uint32_t leaf_meta = super_meta(kSuperLeaf, kSuperLeaf, kSuperLeaf, 0, 0, 0, 0);
   struct Item {
     int32_t node;
     uint32_t slot;   // relative to the tree base
@@ -189,9 +195,10 @@ bool emit_super(const Forest& f, SuperForest* out) {
       const size_t n = (size_t)it.node;
       SuperNode s = unused;
       if (t.left[n] == -1) {
-        // a leaf on top: its value in all three slots, all three feature codes 31 (from `unused`),
-        // so that whichever child slot the walk looks at says "leaf" and holds the value
+        // a leaf on top: its value in all three slots, all three feature codes 31, so that whichever
+        // child slot the walk looks at says "leaf" and holds the value; group 0: fillers from here on
         s.thr0 = s.thrL = s.thrR = t.value[n];
+        s.meta = leaf_meta;
       } else {
         const size_t l = (size_t)t.left[n], r = (size_t)t.right[n];
         const bool l_int = t.left[l] != -1, r_int = t.left[r] != -1;

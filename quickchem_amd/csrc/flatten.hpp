@@ -76,11 +76,13 @@ constexpr uint64_t kPackedMaxSlots = 1ull << 26;
 //                    super-nodes [LL, LR, RL, RR] stored contiguously (64 B)
 // next = tree_base + 4 * group + 2 * go_right(node) + go_right(child)
 //
-// Fillers.  Group 0 of every tree is four filler super-nodes - all three codes 31, all three
-// values +0.0, group 0 - and so is every slot of a group that lies below a leaf.  A lane that has
-// taken its leaf therefore keeps stepping through fillers (and ends up on group 0, shared by all
-// finished lanes of the tree): the kernel needs no per-lane "finished" state, it ORs "the child's
-// value if its code is 31" into the lane's leaf bits - the real leaf once, zero bits afterwards.
+// Fillers.  Group 0 of every tree is four filler super-nodes and so is every slot of a group that lies
+// below a leaf.  A filler looks like an internal node: feature 0 three times, thresholds +inf, default
+// left, group 0 - whatever the row holds, the walk goes on to slot 0 of group 0, and no code of a filler
+// is 31.  A lane that has taken its leaf therefore keeps stepping through fillers (shared by all
+// finished lanes of the tree): the kernel needs no per-lane "finished" state, it keeps "the child's value
+// if its code is 31" - and a walk meets code 31 exactly once, at its leaf (two ALU operations per
+// step; with all-31 fillers of value +0.0 that were OR-ed in it was three).
 // Group 1 is where a walk starts: the root's super-node at slot 4 (phase 0) or the super-nodes of
 // the root's two children at slots 4 and 5 (phase 1).
 struct SuperNode {

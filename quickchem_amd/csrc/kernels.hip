@@ -250,10 +250,10 @@ __device__ __forceinline__ bool go_left_or_default(float x, float thr, bool defa
 }
 
 // One step (two tree levels) of all chains.  There is no "finished" state: a lane that has taken its
-// leaf simply walks on, and emit_super guarantees that it lands on filler super-nodes (all codes 31,
-// all values +0.0, group 0 = four fillers) from then on, so OR-ing "the child's value if its code
-// is 31" into the lane's leaf bits adds the real leaf exactly once and zero bits afterwards.  The
-// fillers of one tree share a cache line or two, so lanes that are done cost the L1 next to nothing.
+// leaf simply walks on, and emit_super guarantees that it lands on filler super-nodes from then on
+// (internal-looking, no code 31, leading to group 0 = four fillers), so "the child's value if its code
+// is 31" is taken exactly once per walk, at the leaf.  The fillers of one tree share a cache line, so
+// lanes that are done cost the L1 next to nothing.
 // LAST: the tree's final step - nothing is fetched after it, only the leaf is taken.
 template <int CHAINS, bool HAS_MISSING, bool LAST>
 __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[CHAINS], uint32_t (&leafb)[CHAINS],
@@ -285,7 +285,7 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
 #pragma unroll
   for (int c = 0; c < CHAINS; ++c) {
     const uint32_t w = s[c].w;
-    leafb[c] |= (f1[c] == 31u) ? thr1[c] : 0u;
+    leafb[c] = (f1[c] == 31u) ? thr1[c] : leafb[c];
     if (!LAST) {
       bool l1 = x1[c] < __uint_as_float(thr1[c]);
       if (HAS_MISSING) l1 = go_left_or_default(x1[c], __uint_as_float(thr1[c]), (w & (l0[c] ? 64u : 128u)) != 0u);

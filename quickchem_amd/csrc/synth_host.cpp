@@ -296,7 +296,7 @@ int ohx_super_walk_cpu(const uint8_t* model, uint64_t model_len, const float* ro
         auto left = [](float xv, float thr, bool dl) { return xv != xv ? dl : xv < thr; };
         uint32_t rel = 4u;
         if (h.root_meta & 0x100u) rel += left(x[h.root_meta & 31u], h.root_thr, (h.root_meta & 32u) != 0) ? 0u : 1u;
-        uint32_t leaf_bits = 0;
+        uint32_t leaf_bits = 0, taken = 0;
         // as walk_super does: the records of the first three steps among the tree's first kSuperTopSlots
         // (its one "top" load); two more steps than the tree has, as when it shares a group of chains with a
         // deeper tree (a walk past its leaf only meets fillers)
@@ -310,13 +310,13 @@ int ohx_super_walk_cpu(const uint8_t* model, uint64_t model_len, const float* ro
           const float thr1 = l0 ? s.thrL : s.thrR;
           const uint32_t f1 = (w >> (l0 ? 0u : 13u)) & 31u;
           if (f1 == 31u) {
-            uint32_t b;
-            memcpy(&b, &thr1, 4);
-            leaf_bits |= b;
+            memcpy(&leaf_bits, &thr1, 4);
+            ++taken;
           }
           const bool l1 = left(x[f1], thr1, ((w >> (l0 ? 6u : 7u)) & 1u) != 0);
           rel = ((w >> 18) << 2) + (l0 ? 0u : 2u) + (l1 ? 0u : 1u);
         }
+        if (taken != 1) throw OhxError("a walk must meet exactly one leaf code, met " + std::to_string(taken));
         float leaf;
         memcpy(&leaf, &leaf_bits, 4);
         acc += leaf;
