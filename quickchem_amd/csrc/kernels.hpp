@@ -111,8 +111,8 @@ struct LaunchTuning {
   // rows in no known order: -1 = decide per matrix (cluster unless the rows look ordered), 0 = never, 1 = always
   int cluster = -1;
   int cluster_trees = 2, cluster_steps = 7, cluster_zorder = 0;
-  // rows API: the grid the rows were gathered from and the grid row the matrix starts at
-  // (XGBoosterSetParam "ohx_grid" = "im,jm[,row0]").  0 = unknown, tiles are 64 consecutive rows.
+  // rows API: the grid the rows were gathered from and the grid row the matrix starts at, filled per call from
+  // the DMatrix (OHXDMatrixSetGrid, or the level size the library found).  0 = unknown: 64 consecutive rows.
   int grid_im = 0, grid_jm = 0;
   uint64_t grid_row0 = 0;
   // log2 extents of a wave's brick; -1 = chosen per call (TileShape::set_grid_auto); all 0 = no bricks
