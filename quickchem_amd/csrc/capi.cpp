@@ -258,7 +258,11 @@ struct BoosterObj {
   ~BoosterObj() {
     if (s_copy) (void)hipStreamDestroy(s_copy);
     if (s_exec) (void)hipStreamDestroy(s_exec);
+    if (train.side) (void)hipStreamDestroy(train.side);
+    if (train.fork) (void)hipEventDestroy(train.fork);
+    if (train.join) (void)hipEventDestroy(train.join);
   }
+  TrainStreams train;              // second stream of the launch train (kernels.hpp), made at upload
   Forest forest;
   bool loaded = false;
   float margin_base = 0.0f;        // Forest::margin_base() of the loaded model
@@ -397,6 +401,12 @@ void ensure_uploaded(BoosterObj& b) {
   if (pick_kernel(b) == KernelKind::Wide) ensure_wide(b);
   b.d_flags.ensure(1);
   HIP_CHECK(hipMemset(b.d_flags.p, 0, sizeof(uint32_t)));
+  if (!b.train.side) {
+    HIP_CHECK(hipStreamCreateWithFlags(&b.train.side, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&b.train.fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&b.train.join, hipEventDisableTiming));
+  }
+  b.tune.train = &b.train;
   b.uploaded = true;
 }
 
@@ -931,6 +941,9 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     b->tune.prefetch = atoi(value) != 0;
   } else if (n == "ohx_xcd_remap") {
     b->tune.xcd_remap = atoi(value) != 0;
+  } else if (n == "ohx_overlap_group") {
+    b->tune.overlap_group = atoi(value);
+    if (b->tune.overlap_group < 0) throw OhxError("ohx_overlap_group must be >= 0");
   } else if (n == "ohx_tree_tops") {
     const std::string v = value;
     if (v != "auto" && v != "on" && v != "off") throw OhxError("ohx_tree_tops must be auto, on or off");

@@ -966,6 +966,47 @@ hipError_t ensure_lds(K kernel, size_t lds_bytes) {
   return hipSuccess;
 }
 
+// Which stream the k-th launch of a train goes to (TrainStreams, kernels.hpp).  Inside a group the launches
+// alternate between the caller's stream and the side stream; at a group's end both streams meet.  Order between
+// launches never matters for the results (disjoint rows); it only shapes how the chip is filled.
+struct TrainCursor {
+  hipStream_t main;
+  const TrainStreams* tr;
+  int group;
+  int k = 0;
+  bool side_open = false;   // the side stream carries launches nobody has waited for yet
+  TrainCursor(hipStream_t m, const LaunchTuning& tune)
+      : main(m), tr((tune.overlap_group >= 2 && tune.train && tune.train->side) ? tune.train : nullptr),
+        group(tune.overlap_group) {}
+  hipError_t meet() {
+    if (!side_open) return hipSuccess;
+    side_open = false;
+    hipError_t e = hipEventRecord(tr->join, tr->side);
+    if (e != hipSuccess) return e;
+    return hipStreamWaitEvent(main, tr->join, 0);
+  }
+  hipError_t next(hipStream_t* out) {
+    *out = main;
+    if (tr == nullptr) return hipSuccess;
+    const int pos = k++ % group;
+    if (pos == 0) {
+      hipError_t e = meet();
+      if (e != hipSuccess) return e;
+    }
+    if (pos & 1) {
+      if (!side_open) {   // the side stream starts behind everything the caller's stream holds so far
+        hipError_t e = hipEventRecord(tr->fork, main);
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(tr->side, tr->fork, 0);
+        if (e != hipSuccess) return e;
+        side_open = true;
+      }
+      *out = tr->side;
+    }
+    return hipSuccess;
+  }
+};
+
 // One launch, or a train of launches of one residency (grid x 4 tiles) each.
 template <class K>
 hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, PredictArgs a, int num_cus,
@@ -992,13 +1033,19 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
     return hipGetLastError();
   }
   const uint64_t per_launch = (uint64_t)grid * kWavesPerBlock * (uint64_t)tune.launches_per_residency;
+  TrainCursor train(stream, tune);
   for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
     a.tile_begin = t0;
     a.tile_end = t0 + per_launch < ntiles ? t0 + per_launch : ntiles;
     const uint64_t blocks = (a.tile_end - a.tile_begin + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipStream_t s;
+    e = train.next(&s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < (uint64_t)grid ? blocks : (uint64_t)grid)), dim3(kBlock), lds,
-                       stream, fr, a, fr.super_heads, a.out);
+                       s, fr, a, fr.super_heads, a.out);
   }
+  e = train.meet();
+  if (e != hipSuccess) return e;
   return hipGetLastError();
 }
 
@@ -1089,13 +1136,19 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
   const uint64_t per_launch = tune.launches_per_residency <= 0
                                   ? ntiles
                                   : (uint64_t)grid * kWavesPerBlock * (uint64_t)tune.launches_per_residency;
+  TrainCursor train(stream, tune);
   for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
     a.tile_begin = t0;
     a.tile_end = t0 + per_launch < ntiles ? t0 + per_launch : ntiles;
     const uint64_t blocks = (a.tile_end - a.tile_begin + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipStream_t s;
+    e = train.next(&s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < (uint64_t)grid ? blocks : (uint64_t)grid)), dim3(kBlock), lds,
-                       stream, fr, a, fr.super_heads, a.out, a.margin_out);
+                       s, fr, a, fr.super_heads, a.out, a.margin_out);
   }
+  e = train.meet();
+  if (e != hipSuccess) return e;
   return hipGetLastError();
 }
 

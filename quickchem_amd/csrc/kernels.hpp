@@ -98,12 +98,24 @@ struct PredictArgs {
   TileShape shape;              // lanes -> rows
 };
 
+// A second stream for the launch train (owned by the booster): launches of a group alternate between the caller's
+// stream and this one, so that the waves of a launch that finish early are replaced by the next launch's at once
+// instead of idling until the last wave of their launch is done (LaunchTuning::overlap_group).
+struct TrainStreams {
+  hipStream_t side = nullptr;      // non-blocking
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
 struct LaunchTuning {
   // 0: one launch for the whole batch (waves stride over tiles).  > 0: one launch per this many
   // "waves of tiles": every launch starts all resident waves on tree 0 together, so the waves of
   // an XCD walk the same few trees at the same time and share their node lines in that XCD's L2.
   int launches_per_residency = 2;
   int xcd_remap = 1;
+  // launches of the train in groups of this many, alternating between two streams inside a group and meeting at
+  // its end (0 or 1 = every launch waits for the one before, as a single stream does)
+  int overlap_group = 0;
+  const TrainStreams* train = nullptr;
   // tree tops (walk_super): -1 = by the forest's mean step count (deep forests), 0 = never, 1 = always
   int tree_tops = -1;
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
