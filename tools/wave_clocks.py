@@ -4,7 +4,7 @@
 Builds an INSTRUMENTED copy of the library in a scratch directory - the product tree is not touched: the rows kernel
 records wall_clock64() at every wave's start, after its first tile and at its end for the first launch of a step
 into a __device__ array, and an extra entry point hands the array out.  Then runs the C360 step and prints where a
-launch's time goes.  usage (GPU box): python3 tools/wave_clocks.py [name=value booster parameters ...]"""
+launch's time goes.  usage (GPU box): python3 tools/wave_clocks.py [--launch k] [name=value booster parameters ...]"""
 import ctypes as C
 import os
 import shutil
@@ -24,14 +24,14 @@ def patch(path, pairs):
     open(path, "w").write(s)
 
 
-def build_instrumented(scratch):
+def build_instrumented(scratch, launch):
     for d in ("quickchem_amd", "include", "oracle"):
         shutil.copytree(os.path.join(ROOT, d), os.path.join(scratch, d), ignore=shutil.ignore_patterns("__pycache__"))
     csrc = os.path.join(scratch, "quickchem_amd", "csrc")
     patch(os.path.join(csrc, "kernels.hip"), [
         ("// ------------------------------------------------------------------ kernels\n",
          "// ------------------------------------------------------------------ kernels\n"
-         "__device__ unsigned long long g_wave_clocks[3 * 8192];\n"),
+         f"#define WAVE_CLOCKS_LAUNCH {launch}\n__device__ unsigned long long g_wave_clocks[3 * 8192];\n"),
         ("  extern __shared__ float lds[];\n  const int lane = threadIdx.x & (kWave - 1);\n  const int wave = threadIdx.x / kWave;\n"
          "  // the waves' feature tiles first",
          "  extern __shared__ float lds[];\n  const int lane = threadIdx.x & (kWave - 1);\n  const int wave = threadIdx.x / kWave;\n"
@@ -40,7 +40,8 @@ def build_instrumented(scratch):
         ("      if (this_valid) __builtin_nontemporal_store(acc, out + this_row);\n      tile_id = next;\n    }\n    return;",
          "      if (this_valid) __builtin_nontemporal_store(acc, out + this_row);\n      tile_id = next;\n"
          "      if (t_mid == 0) t_mid = wall_clock64();\n    }\n"
-         "    if (a.tile_begin == 0 && lane == 0) {\n      const unsigned w = blockIdx.x * kWavesPerBlock + wave;\n"
+         "    if (a.tile_begin == (uint64_t)WAVE_CLOCKS_LAUNCH * (a.tile_end - a.tile_begin) && lane == 0) {\n"
+         "      const unsigned w = blockIdx.x * kWavesPerBlock + wave;\n"
          "      if (w < 8192) { g_wave_clocks[3 * w] = t_start; g_wave_clocks[3 * w + 1] = t_mid; g_wave_clocks[3 * w + 2] = wall_clock64(); }\n"
          "    }\n    return;"),
         ("uint32_t cluster_key_bits(const ClusterArgs& a) {",
@@ -62,7 +63,11 @@ def build_instrumented(scratch):
 
 def main():
     scratch = tempfile.mkdtemp(prefix="ohx_wave_clocks_")
-    build_instrumented(scratch)
+    launch = 0
+    if len(sys.argv) > 2 and sys.argv[1] == "--launch":          # which launch of the step's train to record
+        launch = int(sys.argv[2])
+        del sys.argv[1:3]
+    build_instrumented(scratch, launch)
     sys.path.insert(0, scratch)
     import numpy as np
     import torch
@@ -91,7 +96,7 @@ def main():
     start, mid, end = ((t[:, i] - t0) / 100.0 for i in range(3))       # microseconds: the clock runs at 100 MHz
     pct = lambda a: " ".join(f"p{p} {v:.1f}" for p, v in zip((5, 50, 95), np.percentile(a, [5, 50, 95])))  # noqa: E731
     print(f"{b.kernel_symbol(synth.NFEAT)}  params {sys.argv[1:]}")
-    print(f"first launch of a C360 step: {len(t)} waves, span {end.max():.1f} us; last wave started at {start.max():.1f} us")
+    print(f"launch {launch} of a C360 step: {len(t)} waves, span {end.max():.1f} us; last wave started at {start.max():.1f} us")
     print(f"first tile   mean {np.mean(mid - start):.1f} us  {pct(mid - start)}  max {np.max(mid - start):.1f}")
     print(f"later tiles  mean {np.mean(end - mid):.1f} us  {pct(end - mid)}  max {np.max(end - mid):.1f}")
     print(f"a wave ends  mean {end.mean():.1f} us  {pct(end)}  max {end.max():.1f}")
