@@ -2,7 +2,7 @@
 """Per-wave clocks inside one launch of the rows kernel (measurement aid, not product code).
 
 Builds an INSTRUMENTED copy of the library in a scratch directory - the product tree is not touched: the rows kernel
-records wall_clock64() at every wave's start, after its first tile and at its end for one launch (or round) of a step
+records wall_clock64() at every wave's start, after its first tile and at its end for the first launch of a step
 into a __device__ array, and an extra entry point hands the array out.  Then runs the C360 step and prints where a
 launch's time goes.  usage (GPU box): python3 tools/wave_clocks.py [--launch k] [name=value booster parameters ...]"""
 import ctypes as C
@@ -32,16 +32,18 @@ def build_instrumented(scratch, launch):
         ("// ------------------------------------------------------------------ kernels\n",
          "// ------------------------------------------------------------------ kernels\n"
          f"#define WAVE_CLOCKS_LAUNCH {launch}\n__device__ unsigned long long g_wave_clocks[3 * 8192];\n"),
-        ("      uint64_t tile_id = r_begin + wave_id;\n      Row27 regs;",
-         "      const unsigned long long t_start = wall_clock64();\n      unsigned long long t_mid = 0;\n"
-         "      uint64_t tile_id = r_begin + wave_id;\n      Row27 regs;"),
-        ("        if (this_valid) __builtin_nontemporal_store(acc, out + this_row);\n        tile_id = next;\n      }\n",
-         "        if (this_valid) __builtin_nontemporal_store(acc, out + this_row);\n        tile_id = next;\n"
-         "        if (t_mid == 0) t_mid = wall_clock64();\n      }\n"
-         "      if (r_begin == (uint64_t)WAVE_CLOCKS_LAUNCH * per_round && lane == 0) {\n"
-         "        const unsigned w = blockIdx.x * kWavesPerBlock + wave;\n"
-         "        if (w < 8192) { g_wave_clocks[3 * w] = t_start; g_wave_clocks[3 * w + 1] = t_mid; g_wave_clocks[3 * w + 2] = wall_clock64(); }\n"
-         "      }\n"),
+        ("  extern __shared__ float lds[];\n  const int lane = threadIdx.x & (kWave - 1);\n  const int wave = threadIdx.x / kWave;\n"
+         "  // the waves' feature tiles first",
+         "  extern __shared__ float lds[];\n  const int lane = threadIdx.x & (kWave - 1);\n  const int wave = threadIdx.x / kWave;\n"
+         "  const unsigned long long t_start = wall_clock64();\n  unsigned long long t_mid = 0;\n"
+         "  // the waves' feature tiles first"),
+        ("      if (this_valid) __builtin_nontemporal_store(acc, out + this_row);\n      tile_id = next;\n    }\n    return;",
+         "      if (this_valid) __builtin_nontemporal_store(acc, out + this_row);\n      tile_id = next;\n"
+         "      if (t_mid == 0) t_mid = wall_clock64();\n    }\n"
+         "    if (a.tile_begin == (uint64_t)WAVE_CLOCKS_LAUNCH * (a.tile_end - a.tile_begin) && lane == 0) {\n"
+         "      const unsigned w = blockIdx.x * kWavesPerBlock + wave;\n"
+         "      if (w < 8192) { g_wave_clocks[3 * w] = t_start; g_wave_clocks[3 * w + 1] = t_mid; g_wave_clocks[3 * w + 2] = wall_clock64(); }\n"
+         "    }\n    return;"),
         ("uint32_t cluster_key_bits(const ClusterArgs& a) {",
          "hipError_t debug_wave_clocks(unsigned long long* out) {\n"
          "  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_clocks), sizeof(unsigned long long) * 3 * 8192);\n}\n\n"
