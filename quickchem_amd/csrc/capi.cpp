@@ -939,6 +939,8 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     b->tune.lds_pad = atoi(value);
   } else if (n == "ohx_prefetch") {
     b->tune.prefetch = atoi(value) != 0;
+  } else if (n == "ohx_coop_rows") {
+    b->tune.coop_rows = atoi(value) != 0;
   } else if (n == "ohx_xcd_remap") {
     b->tune.xcd_remap = atoi(value) != 0;
   } else if (n == "ohx_overlap_group") {

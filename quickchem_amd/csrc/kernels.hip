@@ -141,8 +141,7 @@ __device__ __forceinline__ bool fill_tile_rows(float* __restrict__ tile, const f
 // The OH shape (27 columns, 27 features): a row held in registers, so the NEXT tile's rows can
 // be in flight from HBM while the current tile is walked (the walk needs no registers of it).
 struct Row27 {
-  f4u v[6];
-  float t[3];
+  f4u v[7];   // a lane's own row in v[0] .. v[6][2]; or seven 16-byte pieces of the wave's tile (load_pieces)
 };
 
 __device__ __forceinline__ void load_row27(Row27& r, const float* __restrict__ rows, uint64_t row) {
@@ -150,7 +149,7 @@ __device__ __forceinline__ void load_row27(Row27& r, const float* __restrict__ r
 #pragma unroll
   for (int q = 0; q < 6; ++q) r.v[q] = __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p + 4 * q));
 #pragma unroll
-  for (int q = 0; q < 3; ++q) r.t[q] = __builtin_nontemporal_load(p + 24 + q);
+  for (int q = 0; q < 3; ++q) r.v[6][q] = __builtin_nontemporal_load(p + 24 + q);
 }
 
 __device__ __forceinline__ bool store_row27(float* __restrict__ tile, const Row27& r, bool valid, float missing,
@@ -159,7 +158,7 @@ __device__ __forceinline__ bool store_row27(float* __restrict__ tile, const Row2
   const float qnan = __builtin_nanf("");
 #pragma unroll
   for (int f = 0; f < 27; ++f) {
-    float x = f < 24 ? r.v[f / 4][f % 4] : r.t[f - 24];
+    float x = r.v[f / 4][f % 4];
     if (!valid) x = 0.0f;
     any_inf |= is_inf(x);
     if (!missing_is_nan && x == missing) x = qnan;
@@ -167,6 +166,86 @@ __device__ __forceinline__ bool store_row27(float* __restrict__ tile, const Row2
     tile[f * kWave] = x;
   }
   if (any_inf && !is_inf(missing) && flags) atomicOr(flags, kFlagInfInput);
+  return any_nan;
+}
+
+// The same rows fetched by the wave TOGETHER.  A tile of a grid is made of runs of 2^run_log rows that follow each
+// other in memory (a brick's cells along i; all 64 rows where no grid is known): 27 * 2^run_log floats, a multiple of
+// 16 bytes from run_log = 2 on.  Lane l fetches the 16-byte pieces l, l + 64, ... of the tile's 432, whatever
+// rows they belong to: consecutive lanes read consecutive memory, every 64-byte line is asked for once, and a quad
+// of lanes asks the L1 for one or two blocks instead of four to eight - per-row loads made the row stream the
+// texture addresser's second-largest customer.  The pieces go to the tile by element.
+//   run g of a tile: its first row is the row of lane  lane_of(g) = g's low run_lo_bits | rest << (run_lo_bits + run_log)
+//   row r of run g belongs to lane  lane_of(g) | r << run_lo_bits
+// (level-fastest bricks: run_lo_bits = lk; i-fastest and gridless tiles: 0.)
+constexpr uint32_t kPiecesPerTile = kWave * 27u / 4u;   // 432
+
+__device__ __forceinline__ uint32_t div27(uint32_t x) { return (x * 1214u) >> 15; }   // exact below 1728
+
+__device__ __forceinline__ uint32_t run_first_lane(uint32_t g, uint32_t run_log, uint32_t lo_bits) {
+  return (g & ((1u << lo_bits) - 1u)) | ((g >> lo_bits) << (lo_bits + run_log));
+}
+
+// `row`: this lane's own row (launch_row), meaningful or not; the runs' first rows are taken from their lanes
+__device__ __forceinline__ void load_pieces(Row27& r, const PredictArgs& a, uint64_t row, int lane) {
+  // what follows depends on the lane and the launch only: kept from being hoisted out of the tile loop, where it
+  // would sit in some forty registers across the walk
+  asm volatile("" : "+v"(lane));
+  const uint32_t ppr = 27u << (a.run_log - 2u);            // pieces per run
+  const int64_t total = (int64_t)a.nrow * 27;
+  const uint32_t row_lo = (uint32_t)row, row_hi = (uint32_t)(row >> 32);
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const uint32_t p = (uint32_t)lane + 64u * (uint32_t)q;
+    const uint32_t pc = p < kPiecesPerTile ? p : kPiecesPerTile - 1u;
+    const uint32_t g = div27(pc) >> (a.run_log - 2u);
+    const uint32_t w = pc - g * ppr;
+    const int src = (int)(run_first_lane(g, a.run_log, a.run_lo_bits) << 2);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row_lo);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)row_hi);
+    const int64_t first = (int64_t)(((uint64_t)hi << 32) | lo) * 27 + (int64_t)(4u * w);   // float index of the piece
+    // pieces of rows outside the matrix are read from inside it (their lanes carry no row: store_pieces writes
+    // zeros); the tiles that hold the matrix's first or last row are not fetched this way (see the kernel)
+    const int64_t inside = first < 0 ? 0 : (first + 4 > total ? total - 4 : first);
+    r.v[q] = __builtin_nontemporal_load(reinterpret_cast<const f4u*>(a.rows + inside));
+  }
+}
+
+// tile_base: the wave's tile (feature f of lane l at tile_base[f * 64 + l]); vmask: the lanes that carry a row
+__device__ __forceinline__ bool store_pieces(float* __restrict__ tile_base, const Row27& r, const PredictArgs& a,
+                                             uint64_t vmask, int lane, bool missing_is_nan) {
+  bool any_nan = false, any_inf = false;
+  const float qnan = __builtin_nanf("");
+  asm volatile("" : "+v"(lane));   // as in load_pieces
+  const uint32_t ppr = 27u << (a.run_log - 2u);
+  const bool all_valid = vmask == ~0ull;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const uint32_t p = (uint32_t)lane + 64u * (uint32_t)q;
+    if (p < kPiecesPerTile) {
+      const uint32_t g = div27(p) >> (a.run_log - 2u);
+      const uint32_t w4 = 4u * (p - g * ppr);                 // element of the run this piece starts at
+      const uint32_t col0 = run_first_lane(g, a.run_log, a.run_lo_bits);
+      uint32_t rr = div27(w4);
+      uint32_t f = w4 - 27u * rr;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t col = col0 | (rr << a.run_lo_bits);
+        float x = r.v[q][c];
+        if (!all_valid && !((vmask >> col) & 1ull)) x = 0.0f;
+        any_inf |= is_inf(x);
+        if (!missing_is_nan && x == a.missing) x = qnan;
+        any_nan |= (x != x);
+        tile_base[f * kWave + col] = x;
+        ++f;
+        if (f == 27u) {
+          f = 0u;
+          ++rr;
+        }
+      }
+    }
+  }
+  if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
   return any_nan;
 }
 
@@ -482,25 +561,42 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
   if constexpr (PREFETCH27) {
     uint64_t tile_id = a.tile_begin + wave_id;
+    // The wave fetches its tile's rows together where they come in runs (load_pieces), else every lane its own;
+    // so does the tile that holds the matrix's first or last row: a 16-byte piece of those could hang over the
+    // end of the caller's buffer.
+    float* tile_base = tile - lane;
     Row27 regs;
-    bool valid = false;
+    bool valid = false, together = false;
     uint64_t row = 0;
     if (tile_id < a.tile_end) {
       row = launch_row(a, tile_id, lane, &valid);
-      load_row27(regs, a.rows, valid ? row : 0);
+      together = a.run_log >= 2u && !__any(valid && (row == 0 || row + 1 == a.nrow));
+      if (together) load_pieces(regs, a, row, lane);
+      else load_row27(regs, a.rows, valid ? row : 0);
     }
     while (tile_id < a.tile_end) {
-      const bool lane_nan = store_row27(tile, regs, valid, a.missing, missing_is_nan, a.flags);
+      const bool lane_nan = together ? store_pieces(tile_base, regs, a, __ballot(valid), lane, missing_is_nan)
+                                     : store_row27(tile, regs, valid, a.missing, missing_is_nan, a.flags);
       const uint64_t next = tile_id + nwaves;
       const uint64_t this_row = row;
       const bool this_valid = valid;
       if (next < a.tile_end) {
         row = launch_row(a, next, lane, &valid);
-        load_row27(regs, a.rows, valid ? row : 0);   // in flight during the walk
+        together = a.run_log >= 2u && !__any(valid && (row == 0 || row + 1 == a.nrow));
+        if (together) load_pieces(regs, a, row, lane);   // in flight during the walk
+        else load_row27(regs, a.rows, valid ? row : 0);
       }
       const bool wave_nan = __any(lane_nan);
+      // fetched together, the tile was written by all lanes for all lanes: LDS serves a wave's instructions in
+      // order; the fences and the wave barriers keep the compiler from moving reads and writes across
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
       if (this_valid) __builtin_nontemporal_store(acc, out + this_row);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       tile_id = next;
     }
     return;
@@ -1026,6 +1122,17 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
   const uint64_t ntiles = a.shape.ntiles(a.nrow);
   const int grid = tile_grid(kernel, lds, ntiles, num_cus);
   a.xcd_remap = tune.xcd_remap;
+  // runs of consecutive rows inside a tile (load_pieces): a brick's cells along i, or all 64 rows without a grid
+  a.run_log = 0;
+  a.run_lo_bits = 0;
+  if (tune.coop_rows && a.perm == nullptr && a.ncol == 27) {
+    if (a.shape.im == 0) {
+      a.run_log = 6;
+    } else if (a.shape.li >= 2) {
+      a.run_log = a.shape.li;
+      a.run_lo_bits = a.shape.k_fastest ? a.shape.lk : 0u;
+    }
+  }
   if (tune.launches_per_residency <= 0) {
     a.tile_begin = 0;
     a.tile_end = ntiles;

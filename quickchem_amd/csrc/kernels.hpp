@@ -95,6 +95,9 @@ struct PredictArgs {
   uint64_t tile_end = 0;        // one past the last tile of this launch
   int xcd_remap = 1;            // give each XCD a contiguous range of tiles
   const uint32_t* perm = nullptr;  // rows grouped by the clustering pass: lane l of tile t takes row perm[64 t + l]
+  // 27-column rows of a tile fetched by the wave together, run of consecutive rows by run (kernels.hip RowPieces):
+  // log2 of the rows per run (0 = every lane fetches its own row), and where a run's rows sit among the lanes
+  uint32_t run_log = 0, run_lo_bits = 0;
   TileShape shape;              // lanes -> rows
 };
 
@@ -119,6 +122,7 @@ struct LaunchTuning {
   // tree tops (walk_super): -1 = by the forest's mean step count (deep forests), 0 = never, 1 = always
   int tree_tops = -1;
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
+  int coop_rows = 1;  // ... fetched by the wave together where a tile is made of runs of >= 4 consecutive rows
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
   // rows in no known order: -1 = decide per matrix (cluster unless the rows look ordered), 0 = never, 1 = always
   int cluster = -1;
