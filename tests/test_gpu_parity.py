@@ -531,3 +531,43 @@ def test_tree_tops_walk_gives_the_same_margins(torch_cuda, small_model, deep_mod
         b.free()
     with pytest.raises(capi.OhxError, match="ohx_tree_tops"):
         capi.Booster(model_buffer=hand).set_param("ohx_tree_tops", "maybe")
+
+
+@pytest.mark.parametrize("shape", [(12, 72, 9), (20, 7, 5), (4, 4, 72), (64, 3, 2)])
+def test_rows_fetched_together_or_lane_by_lane(torch_cuda, shape, small_model):
+    """ohx_coop_rows: the wave fetches its tile's rows as 16-byte pieces of the runs of consecutive rows and scatters
+    them to the tile (default), or every lane fetches its own row.  Same margins - device matrices of exactly
+    nrow x 27 floats (a piece must never be read from beyond them), shards that start and end anywhere, one-row
+    and 63-row matrices, both lane orders, the brick shapes with runs of 4, 8 and 64 rows, no grid at all, missing
+    values."""
+    torch = torch_cuda
+    im, jm, nk = shape
+    n = im * jm * nk
+    rows = with_missing(synth.rows_cpu((im, jm, max(nk, 2)), 0, n), 0.003)
+    want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
+    plane = im * jm
+    cases = [(0, n), (plane // 3 + 1, n - plane // 3 - plane // 2 - 2), (n - 1, 1), (5, 63), (0, 65), (n - 130, 129)]
+    for r0, m in cases:
+        if m < 1 or r0 < 0 or r0 + m > n:
+            continue
+        d_rows = torch.from_numpy(rows[r0:r0 + m].copy()).to("cuda:0")
+        out = torch.empty(m, dtype=torch.float32, device="cuda:0")
+        for grid in ((im, jm, r0), None):
+            for coop in ("1", "0"):
+                for kf, brick in (("1", "auto"), ("0", "auto"), ("1", "8,4,2"), ("0", "8,8,1"), ("1", "64,1,1")):
+                    if grid is None and (kf, brick) != ("1", "auto"):
+                        continue
+                    b = capi.Booster(model_buffer=small_model.image)
+                    for k, v in (("ohx_coop_rows", coop), ("ohx_brick_k_fastest", kf), ("ohx_brick", brick)):
+                        if not (k == "ohx_brick" and v == "auto"):
+                            b.set_param(k, v)
+                    d = capi.DMatrix(device_ptr=d_rows.data_ptr(), nrow=m, ncol=27, missing=synth.XX_MISS)
+                    d.set_grid(*grid) if grid else d.set_grid(0, 0, 0)
+                    out.fill_(7.0)
+                    b.predict_device(d, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    b.check()
+                    assert np.array_equal(helpers.bits(out.cpu().numpy()), helpers.bits(want[r0:r0 + m])), \
+                        (r0, m, grid, coop, kf, brick)
+                    d.free()
+                    b.free()
