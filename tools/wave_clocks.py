@@ -31,22 +31,25 @@ def build_instrumented(scratch, launch):
     patch(os.path.join(csrc, "kernels.hip"), [
         ("// ------------------------------------------------------------------ kernels\n",
          "// ------------------------------------------------------------------ kernels\n"
-         f"#define WAVE_CLOCKS_LAUNCH {launch}\n__device__ unsigned long long g_wave_clocks[3 * 8192];\n"),
+         f"#define WAVE_CLOCKS_LAUNCH {launch}\n__device__ unsigned long long g_wave_clocks[4 * 8192];\n"),
         ("  extern __shared__ float lds[];\n  const int lane = threadIdx.x & (kWave - 1);\n  const int wave = threadIdx.x / kWave;\n"
          "  // the waves' feature tiles first",
          "  extern __shared__ float lds[];\n  const int lane = threadIdx.x & (kWave - 1);\n  const int wave = threadIdx.x / kWave;\n"
-         "  const unsigned long long t_start = wall_clock64();\n  unsigned long long t_mid = 0;\n"
+         "  const unsigned long long t_start = wall_clock64();\n  unsigned long long t_mid = 0, t_fill = 0;\n"
          "  // the waves' feature tiles first"),
-        ("      if (this_valid) __builtin_nontemporal_store(acc, out + this_row);\n      tile_id = next;\n    }\n    return;",
-         "      if (this_valid) __builtin_nontemporal_store(acc, out + this_row);\n      tile_id = next;\n"
+        ("      const uint64_t next = tile_id + nwaves;\n      const uint64_t this_row = row;",
+         "      if (t_fill == 0) t_fill = wall_clock64();\n"
+         "      const uint64_t next = tile_id + nwaves;\n      const uint64_t this_row = row;"),
+        ("      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n      tile_id = next;\n    }\n    return;",
+         "      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n      tile_id = next;\n"
          "      if (t_mid == 0) t_mid = wall_clock64();\n    }\n"
          "    if (a.tile_begin == (uint64_t)WAVE_CLOCKS_LAUNCH * (a.tile_end - a.tile_begin) && lane == 0) {\n"
          "      const unsigned w = blockIdx.x * kWavesPerBlock + wave;\n"
-         "      if (w < 8192) { g_wave_clocks[3 * w] = t_start; g_wave_clocks[3 * w + 1] = t_mid; g_wave_clocks[3 * w + 2] = wall_clock64(); }\n"
+         "      if (w < 8192) { g_wave_clocks[4 * w] = t_start; g_wave_clocks[4 * w + 1] = t_mid; g_wave_clocks[4 * w + 2] = wall_clock64(); g_wave_clocks[4 * w + 3] = t_fill; }\n"
          "    }\n    return;"),
         ("uint32_t cluster_key_bits(const ClusterArgs& a) {",
          "hipError_t debug_wave_clocks(unsigned long long* out) {\n"
-         "  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_clocks), sizeof(unsigned long long) * 3 * 8192);\n}\n\n"
+         "  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_clocks), sizeof(unsigned long long) * 4 * 8192);\n}\n\n"
          "uint32_t cluster_key_bits(const ClusterArgs& a) {"),
     ])
     patch(os.path.join(csrc, "kernels.hpp"), [
@@ -88,15 +91,16 @@ def main():
     for _ in range(3):
         b.predict_device(d, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (3 * 8192))()
+    buf = (C.c_ulonglong * (4 * 8192))()
     capi.check(b.lib, b.lib.OHXDebugWaveClocks(buf))
-    t = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 3).astype(np.float64)
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4).astype(np.float64)
     t = t[t[:, 2] > 0]
     t0 = t[:, 0].min()
-    start, mid, end = ((t[:, i] - t0) / 100.0 for i in range(3))       # microseconds: the clock runs at 100 MHz
+    start, mid, end, fill = ((t[:, i] - t0) / 100.0 for i in range(4))  # microseconds: the clock runs at 100 MHz
     pct = lambda a: " ".join(f"p{p} {v:.1f}" for p, v in zip((5, 50, 95), np.percentile(a, [5, 50, 95])))  # noqa: E731
     print(f"{b.kernel_symbol(synth.NFEAT)}  params {sys.argv[1:]}")
     print(f"launch {launch} of a C360 step: {len(t)} waves, span {end.max():.1f} us; last wave started at {start.max():.1f} us")
+    print(f"its rows are in LDS after mean {np.mean(fill - start):.1f} us  {pct(fill - start)}  max {np.max(fill - start):.1f}")
     print(f"first tile   mean {np.mean(mid - start):.1f} us  {pct(mid - start)}  max {np.max(mid - start):.1f}")
     print(f"later tiles  mean {np.mean(end - mid):.1f} us  {pct(end - mid)}  max {np.max(end - mid):.1f}")
     print(f"a wave ends  mean {end.mean():.1f} us  {pct(end)}  max {end.max():.1f}")
