@@ -101,7 +101,7 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *                     the first trees before walking them ("ohx_cluster_trees", "ohx_cluster_steps",
  *                     "ohx_cluster_zorder" shape the key)
  *   "ohx_launches_per_residency"  tiles per wave per launch (default 2; 0 = one launch)
- *   "ohx_brick" = "a,b,c", "ohx_brick_k_fastest", "ohx_prefetch", "ohx_xcd_remap", "ohx_lds_pad", "ohx_overlap_group"
+ *   "ohx_brick" = "a,b,c", "ohx_brick_k_fastest", "ohx_prefetch", "ohx_coop_rows", "ohx_xcd_remap", "ohx_lds_pad", "ohx_overlap_group"
  *                     launch-shape knobs behind profiles/ *_sweeps.txt; the defaults are the measured best
  *   "ohx_top_levels", "ohx_line_slots", "ohx_min_chunk"  placement of the packed format
  *   "ohx_device"      HIP device ordinal for this booster
