@@ -571,3 +571,13 @@ def test_rows_fetched_together_or_lane_by_lane(torch_cuda, shape, small_model):
                         (r0, m, grid, coop, kf, brick)
                     d.free()
                     b.free()
+
+
+def test_random_grids_shards_and_brick_shapes(torch_cuda):
+    """tools/fuzz_tiles.py: random grids, shards, brick shapes, lane orders and launch shapes on device buffers of
+    exactly nrow x 27 floats, against the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_tiles", os.path.join(helpers.ROOT, "tools", "fuzz_tiles.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.run(150, 20261004) == []

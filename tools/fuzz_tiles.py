@@ -15,14 +15,14 @@ from quickchem_amd import capi, synth  # noqa: E402
 from tests import helpers  # noqa: E402
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def run(cases, seed):
+    """Returns the descriptions of the cases whose margins differ from the oracle's."""
+    rng = np.random.default_rng(seed)
     torch.cuda.set_device(0)
     model = synth.make_model(num_trees=12, max_depth=9, sample_log2=13, min_leaf=2, grid=synth.GRIDS["C12"])
     deep = synth.make_model(num_trees=6, max_depth=16, sample_log2=14, min_leaf=1, grid=synth.GRIDS["C12"])
     bricks = ["auto", "4,4,4", "8,4,2", "8,8,1", "2,2,16", "64,1,1", "16,1,4", "4,16,1", "1,8,8"]
-    bad = 0
+    bad = []
     for c in range(cases):
         im, jm, nk = int(rng.integers(1, 70)), int(rng.integers(1, 40)), int(rng.integers(1, 12))
         n = im * jm * nk
@@ -54,11 +54,18 @@ def main():
         torch.cuda.synchronize()
         b.check()
         if not np.array_equal(helpers.bits(out.cpu().numpy()), helpers.bits(want)):
-            bad += 1
-            print("MISMATCH", (im, jm, nk), (r0, m), mode, params)
+            bad.append(((im, jm, nk), (r0, m), mode, params))
         d.free()
         b.free()
-    print(f"{cases} cases, {bad} mismatches")
+    return bad
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    bad = run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    for b in bad:
+        print("MISMATCH", *b)
+    print(f"{cases} cases, {len(bad)} mismatches")
     sys.exit(1 if bad else 0)
 
 
