@@ -323,9 +323,12 @@ __device__ __forceinline__ float walk_wide_tile(const uint4* __restrict__ nodes,
 // the other chains' gathers in flight behind a counted vmcnt.
 
 __device__ __forceinline__ bool go_left_or_default(float x, float thr, bool default_left) {
+  // three compares whose results stay lane masks in scalar registers and meet in two scalar operations (as
+  // integers in vector registers, the way this was first written, a decision cost eight vector instructions and
+  // a batch with missing values walked 46 % slower than one without)
   const bool lt = x < thr;
-  const bool not_ge = !(x >= thr);
-  return (bool)((int)(not_ge & default_left) | (int)(lt & !default_left));
+  const bool missing = x != x;     // a split condition is never NaN
+  return lt | (missing & default_left);
 }
 
 // One step (two tree levels) of all chains.  There is no "finished" state: a lane that has taken its
