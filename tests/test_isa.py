@@ -45,7 +45,8 @@ def test_no_flat_loads_and_no_scratch_anywhere(isa):
 def test_default_walk_kernel_shape(isa):
     body = kernel_body(isa, DEFAULT_KERNEL)
     assert body.count("ds_read_b128") >= 4                      # first-step table: two chains x with/without missing values
-    assert body.count("global_load_dwordx4") >= 16
+    assert body.count("global_load_dwordx4") >= 16              # the rows' pieces, the tree tops
+    assert body.count("buffer_load_dwordx4") >= 4               # the gathers below the tops: one 128-bit load each
     # two chains x two steps x four dwords, with and without missing values; a few more where a tree is beyond the table
     assert body.count("ds_bpermute_b32") >= 32
     vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", body).group(1))
