@@ -13,7 +13,7 @@ grep "^{\"metric\"" $O/bench_under_rocprof.log | tail -1 > $O/bench.json
 cp $O/trace/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 timeout -k 10 600 python3 bench.py > $O/bench_plain.log 2>&1
 grep "^{\"metric\"" $O/bench_plain.log | tail -1 > $O/bench_plain.json
-tools/pmc.sh $tag --no-verify > /dev/null 2>&1
+PMC_KERNEL=predict_rows_tile_kernel tools/pmc.sh $tag > /dev/null 2>&1
 cp gpurun_out/pmc_$tag/summary.txt $O/pmc_summary.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/calib_$c -- python3 bench.py --cpu-seconds 0 --no-verify --steps 2 --warmup 1 --trees 1 --depth 0 > $O/calib_$c.log 2>&1
