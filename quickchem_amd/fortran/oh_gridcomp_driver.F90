@@ -1,6 +1,8 @@
 !  oh_gridcomp_driver -- a mock GEOS cap around QuickChem: BASELINE.json config #1, "a synthetic MAPL state
 !  through OH_GridComp Run".  SetServices of the parent (which creates the OH instances), Initialize, then
-!  `nticks` heartbeats of Run phase 1, Run phase 2 and clock advance, on mapl_lite.  No MAPL, no ESMF.
+!  `nticks` heartbeats of Run phase 1, Run phase 2 and clock advance, through the ESMF / MAPL calls a cap makes, served by
+!  the mock in mapl_lite/ (no MAPL, no ESMF here).  Being the mock's cap it also plays "the rest of GEOS": storage for
+!  the imports, HISTORY's wish list of exports, the model moving between heartbeats (esmfl_ / mapll_ calls).
 !
 !  usage: oh_gridcomp_driver <run dir> <state.bin> <out.bin> <nticks>
 !
@@ -23,25 +25,32 @@
 !  per data instance: real32 INTERNAL OH(im,jm,km).
 program oh_gridcomp_driver
    use, intrinsic :: iso_c_binding
-   use mapl_lite
+   use ESMF
+   use MAPL
    use QuickChem_GridCompMod, only: QuickChem_SetServices => SetServices, IS_QC_INSTANCE_RUNNING
    use OH_GridCompMod, only: oh_last_run
    implicit none
 
-   character(len=ML_MAXPATH) :: rundir, state_file, out_file, arg, model_file
+   character(len=ESMF_MAXPATHLEN) :: rundir, state_file, out_file, arg, model_file
    character(len=32) :: recname
-   character(len=ML_MAXSTR) :: tok
-   character(len=ML_MAXSTR), allocatable :: want(:)
-   type(ml_config), pointer :: agcm
-   type(ml_gridcomp), pointer :: root, child
-   type(ml_grid) :: grid
-   type(ml_clock) :: clock
+   character(len=ESMF_MAXSTR) :: tok, child_name
+   character(len=ESMF_MAXSTR), allocatable :: want(:)
+   type(ESMF_Config) :: agcm
+   type(ESMF_GridComp) :: root
+   type(ESMF_GridComp), pointer :: gcs(:)
+   type(ESMF_State), pointer :: gim(:), gex(:)
+   type(ESMF_State) :: internal
+   type(MAPL_MetaComp), pointer :: meta, cmeta
+   type(ESMF_Grid) :: grid
+   type(ESMF_Clock) :: clock
+   type(ESMF_Time) :: start, now
+   type(ESMF_TimeInterval) :: heartbeat
    integer(c_int32_t) :: im, jm, km, n4, nrec, kind
    integer :: rc, u, uo, nticks, tick, i, c, q, beg_date, beg_time, dt, nymd, nhms, yy, mm, dd, h, m, s, nwant, trc
    integer :: avg24_tick, k1, k2, ninst
    logical :: ran, boosted, running
    real, pointer :: p2(:,:), p3(:,:,:), p4(:,:,:,:), oh(:,:,:), parent_oh(:,:,:)
-   real, allocatable :: buf(:)
+   real, allocatable :: buf(:), lats(:,:), lons(:,:)
 
    if (command_argument_count() < 4) then
       print *, 'usage: oh_gridcomp_driver <run dir> <state.bin> <out.bin> <nticks>'
@@ -53,51 +62,56 @@ program oh_gridcomp_driver
    call get_command_argument(4, arg)
    read(arg, *) nticks
 
-   allocate(agcm)
-   call agcm%load(trim(rundir)//'/AGCM.rc', rc)
-   if (rc /= ML_SUCCESS) call die('cannot read AGCM.rc in '//trim(rundir))
-   call agcm%get_int(dt, 'RUN_DT:', rc, default=450)
-   call agcm%find_label('BEG_DATE:', rc)
-   if (rc /= ML_SUCCESS) call die('AGCM.rc: BEG_DATE: yyyymmdd hhmmss is missing')
-   call agcm%next_token(tok, rc); read(tok, *) beg_date
-   call agcm%next_token(tok, rc); read(tok, *) beg_time
-   call agcm%get_int(avg24_tick, 'AVG24_READY_TICK:', rc, default=-1)
-   nwant = agcm%get_len('OH_EXPORTS:', rc)
-   if (rc /= ML_SUCCESS) nwant = 0
+   call esmfl_set_run_dir(trim(rundir))                 ! GEOS runs in its run directory: resource files are found there
+   agcm = ESMF_ConfigCreate(rc=rc)
+   call ESMF_ConfigLoadFile(agcm, 'AGCM.rc', rc=rc)
+   if (rc /= ESMF_SUCCESS) call die('cannot read AGCM.rc in '//trim(rundir))
+   call ESMF_ConfigGetAttribute(agcm, dt, label='RUN_DT:', default=450, rc=rc)
+   call ESMF_ConfigFindLabel(agcm, 'BEG_DATE:', rc=rc)
+   if (rc /= ESMF_SUCCESS) call die('AGCM.rc: BEG_DATE: yyyymmdd hhmmss is missing')
+   call ESMF_ConfigGetAttribute(agcm, beg_date, rc=rc)
+   call ESMF_ConfigGetAttribute(agcm, beg_time, rc=rc)
+   call ESMF_ConfigGetAttribute(agcm, avg24_tick, label='AVG24_READY_TICK:', default=-1, rc=rc)
+   nwant = ESMF_ConfigGetLen(agcm, label='OH_EXPORTS:', rc=rc)
+   if (rc /= ESMF_SUCCESS) nwant = 0
    allocate(want(max(nwant, 0)))
    if (nwant > 0) then
-      call agcm%find_label('OH_EXPORTS:', rc)
+      call ESMF_ConfigFindLabel(agcm, 'OH_EXPORTS:', rc=rc)
       do i = 1, nwant
-         call agcm%next_token(want(i), rc)
+         call ESMF_ConfigGetAttribute(agcm, want(i), rc=rc)
       end do
    end if
 
    open(newunit=u, file=trim(state_file), access='stream', form='unformatted', status='old', action='read')
    read(u) im, jm, km, n4, nrec
-   grid%im = im; grid%jm = jm; grid%km = km
-   allocate(grid%LATS(im, jm), grid%LONS(im, jm))
-   read(u) grid%LATS
-   read(u) grid%LONS
+   allocate(lats(im, jm), lons(im, jm))
+   read(u) lats
+   read(u) lons
+   grid = esmfl_grid_create(int(im), int(jm), int(km), lats, lons)
 
-   call clock%set(beg_date / 10000, mod(beg_date, 10000) / 100, mod(beg_date, 100), &
-                  beg_time / 10000, mod(beg_time, 10000) / 100, mod(beg_time, 100), dt)
+   call ESMF_TimeSet(start, YY=beg_date / 10000, MM=mod(beg_date, 10000) / 100, DD=mod(beg_date, 100), &
+                     H=beg_time / 10000, M=mod(beg_time, 10000) / 100, S=mod(beg_time, 100))
+   call ESMF_TimeIntervalSet(heartbeat, S=dt)
+   clock = ESMF_ClockCreate(timeStep=heartbeat, startTime=start, rc=rc)
 
-   root => ml_gridcomp_create('QUICKCHEM', agcm, grid, trim(rundir))
-   call QuickChem_SetServices(root, rc)
-   if (rc /= ML_SUCCESS) call die('QuickChem SetServices failed')
-   call IS_QC_INSTANCE_RUNNING('OH', root%children(1)%gc%name, running, rc, rc_dir=trim(rundir))
-   if (rc /= ML_SUCCESS .or. .not. running) call die('IS_QC_INSTANCE_RUNNING does not know the first OH instance')
+   root = ESMF_GridCompCreate(name='QUICKCHEM', config=agcm, grid=grid, rc=rc)
+   call ESMF_GridCompSetServices(root, QuickChem_SetServices, rc=rc)
+   if (rc /= ESMF_SUCCESS) call die('QuickChem SetServices failed')
+   call MAPL_GetObjectFromGC(root, meta, rc)
+   call MAPL_Get(meta, gcs=gcs, gim=gim, gex=gex, rc=rc)
+   call ESMF_GridCompGet(gcs(1), name=child_name)
+   call IS_QC_INSTANCE_RUNNING('OH', trim(child_name), running, rc)
+   if (rc /= ESMF_SUCCESS .or. .not. running) call die('IS_QC_INSTANCE_RUNNING does not know the first OH instance')
 
    !  the rest of GEOS: storage for every import, filled from the state file by name; HISTORY: the exports asked for
-   do c = 1, root%nchildren
-      child => root%children(c)%gc
-      do i = 1, child%import%n
-         call child%import%allocate_field(child%import%f(i)%name, grid, rc)
+   do c = 1, size(gcs)
+      do i = 1, gim(c)%p%n
+         call esmfl_state_allocate(gim(c), gim(c)%p%f(i)%name, grid, rc)
       end do
-      if (index(child%name, 'data') == 0) then
+      if (.not. is_data(c)) then
          do i = 1, nwant
-            call child%export%allocate_field(trim(want(i)), grid, rc)
-            if (rc /= ML_SUCCESS) call die('OH_EXPORTS names an export OH does not have: '//trim(want(i)))
+            call esmfl_state_allocate(gex(c), trim(want(i)), grid, rc)
+            if (rc /= ESMF_SUCCESS) call die('OH_EXPORTS names an export OH does not have: '//trim(want(i)))
          end do
       end if
    end do
@@ -111,68 +125,69 @@ program oh_gridcomp_driver
       case default; call die('state file: unknown record kind')
       end select
       read(u) buf
-      do c = 1, root%nchildren
-         child => root%children(c)%gc
-         if (.not. child%import%has(trim(recname))) cycle
+      do c = 1, size(gcs)
+         if (esmfl_state_index(gim(c), trim(recname)) == 0) cycle
          select case (kind)
          case (2)
-            call child%import%get_pointer(p2, trim(recname), rc)
-            if (rc == ML_SUCCESS) p2 = reshape(buf, shape(p2))
+            call MAPL_GetPointer(gim(c), p2, trim(recname), rc=rc)
+            if (rc == ESMF_SUCCESS) p2 = reshape(buf, shape(p2))
          case (3, 4)
-            call child%import%get_pointer(p3, trim(recname), rc)
-            if (rc == ML_SUCCESS) p3 = reshape(buf, shape(p3))
+            call MAPL_GetPointer(gim(c), p3, trim(recname), rc=rc)
+            if (rc == ESMF_SUCCESS) p3 = reshape(buf, shape(p3))
          case (5)
-            call child%import%get_pointer(p4, trim(recname), rc)
-            if (rc == ML_SUCCESS) p4 = reshape(buf, shape(p4))
+            call MAPL_GetPointer(gim(c), p4, trim(recname), rc=rc)
+            if (rc == ESMF_SUCCESS) p4 = reshape(buf, shape(p4))
          end select
-         if (rc /= ML_SUCCESS) call die('state file: record '//trim(recname)//' does not fit the import of that name')
+         if (rc /= ESMF_SUCCESS) call die('state file: record '//trim(recname)//' does not fit the import of that name')
       end do
       deallocate(buf)
    end do
    close(u)
 
-   call ml_gridcomp_initialize(root, clock, rc)
-   if (rc /= ML_SUCCESS) call die('Initialize failed')
+   call ESMF_GridCompInitialize(root, clock=clock, rc=rc)
+   if (rc /= ESMF_SUCCESS) call die('Initialize failed')
 
-   ninst = root%nchildren
+   ninst = size(gcs)
    open(newunit=uo, file=trim(out_file), access='stream', form='unformatted', status='replace', action='write')
    write(uo) int(nticks, c_int32_t), int(ninst, c_int32_t), int(nwant, c_int32_t)
    do tick = 0, nticks - 1
       if (tick > 0) call model_moves()
       if (tick == avg24_tick) call daily_means_arrive()
-      call ml_gridcomp_run(root, clock, 1, rc)
-      if (rc /= ML_SUCCESS) call die('Run phase 1 failed')
-      call ml_gridcomp_run(root, clock, 2, rc)
-      if (rc /= ML_SUCCESS) call die('Run phase 2 failed')
-      call clock%get(yy, mm, dd, h, m, s)
-      call ml_pack_time(nymd, yy, mm, dd)
-      call ml_pack_time(nhms, h, m, s)
+      call ESMF_GridCompRun(root, clock=clock, phase=1, rc=rc)
+      if (rc /= ESMF_SUCCESS) call die('Run phase 1 failed')
+      call ESMF_GridCompRun(root, clock=clock, phase=2, rc=rc)
+      if (rc /= ESMF_SUCCESS) call die('Run phase 2 failed')
+      call ESMF_ClockGet(clock, currTime=now)
+      call ESMF_TimeGet(now, YY=yy, MM=mm, DD=dd, H=h, M=m, S=s)
+      call MAPL_PackTime(nymd, yy, mm, dd)
+      call MAPL_PackTime(nhms, h, m, s)
       write(uo) int(tick, c_int32_t), int(nymd, c_int32_t), int(nhms, c_int32_t)
-      do c = 1, root%nchildren
-         child => root%children(c)%gc
-         call child%internal%get_pointer(oh, 'OH', rc)
-         if (index(child%name, 'data') > 0) then
+      do c = 1, size(gcs)
+         call MAPL_GetObjectFromGC(gcs(c), cmeta, rc)
+         call MAPL_Get(cmeta, INTERNAL_ESMF_STATE=internal, rc=rc)
+         call MAPL_GetPointer(internal, oh, 'OH', rc=rc)
+         if (is_data(c)) then
             write(uo) oh
             cycle
          end if
-         call oh_last_run(child, ran, boosted, model_file, k1, k2)
+         call oh_last_run(gcs(c), ran, boosted, model_file, k1, k2)
          write(uo) merge(1_c_int32_t, 0_c_int32_t, ran), merge(1_c_int32_t, 0_c_int32_t, boosted), &
                    int(k1, c_int32_t), int(k2, c_int32_t)
          write(uo) model_file(1:256)
          write(uo) oh
          !  what GEOS_ChemGridComp's other children would connect to: the parent's export OH
-         call ml_child_export_field(root, 'OH', parent_oh, trc)
-         write(uo) merge(1_c_int32_t, 0_c_int32_t, trc == ML_SUCCESS .and. c == 1 .and. associated(parent_oh, oh))
+         call mapll_child_export_field(root, 'OH', parent_oh, trc)
+         write(uo) merge(1_c_int32_t, 0_c_int32_t, trc == ESMF_SUCCESS .and. c == 1 .and. associated(parent_oh, oh))
          do i = 1, nwant
-            q = child%export%index_of(trim(want(i)))
-            if (child%export%f(q)%dims == ML_DIMS_HORZ_ONLY) then
-               write(uo) child%export%f(q)%p2
+            q = esmfl_state_index(gex(c), trim(want(i)))
+            if (gex(c)%p%f(q)%dims == MAPL_DimsHorzOnly) then
+               write(uo) gex(c)%p%f(q)%p2
             else
-               write(uo) child%export%f(q)%p3
+               write(uo) gex(c)%p%f(q)%p3
             end if
          end do
       end do
-      call ml_advance(root, clock)
+      call ESMF_ClockAdvance(clock, rc=rc)             ! AFTER the run methods; re-evaluates every run alarm
    end do
    close(uo)
 
@@ -184,43 +199,49 @@ contains
       stop 1
    end subroutine
 
+   logical function is_data(cc)
+      integer, intent(in) :: cc
+      character(len=ESMF_MAXSTR) :: nm
+      call ESMF_GridCompGet(gcs(cc), name=nm)
+      is_data = index(nm, 'data') > 0
+   end function
+
    !  the model state of every computational instance drifts between heartbeats
    subroutine model_moves()
       integer :: cc, r
       real, pointer :: t(:,:,:), tp(:,:)
-      do cc = 1, root%nchildren
-         if (index(root%children(cc)%gc%name, 'data') > 0) cycle
-         call root%children(cc)%gc%import%get_pointer(t, 'T', r)
-         if (r == ML_SUCCESS .and. associated(t)) t = t * 1.0005
-         call root%children(cc)%gc%import%get_pointer(tp, 'TROPP', r)
-         if (r == ML_SUCCESS .and. associated(tp)) tp = tp * 1.002
+      do cc = 1, size(gcs)
+         if (is_data(cc)) cycle
+         call MAPL_GetPointer(gim(cc), t, 'T', rc=r)
+         if (r == ESMF_SUCCESS .and. associated(t)) t = t * 1.0005
+         call MAPL_GetPointer(gim(cc), tp, 'TROPP', rc=r)
+         if (r == ESMF_SUCCESS .and. associated(tp)) tp = tp * 1.002
       end do
    end subroutine
 
    !  the couplers deliver the first complete daily means: X_avg24 = X * 0.99 for every import that has one
    subroutine daily_means_arrive()
       integer :: cc, ii, r, n
-      character(len=ML_MAXSTR) :: base
+      character(len=ESMF_MAXSTR) :: base, name
       real, pointer :: a3(:,:,:), b3(:,:,:), a4(:,:,:,:), b4(:,:,:,:)
-      do cc = 1, root%nchildren
-         associate (imp => root%children(cc)%gc%import)
-            do ii = 1, imp%n
-               n = len_trim(imp%f(ii)%name)
-               if (n <= 6) cycle
-               if (imp%f(ii)%name(n-5:n) /= '_avg24') cycle
-               base = imp%f(ii)%name(1:n-6)
-               if (.not. imp%has(trim(base))) cycle
-               if (imp%f(ii)%ungridded > 0) then
-                  call imp%get_pointer(a4, trim(imp%f(ii)%name), r)
-                  call imp%get_pointer(b4, trim(base), r)
-                  a4 = b4 * 0.99
-               else
-                  call imp%get_pointer(a3, trim(imp%f(ii)%name), r)
-                  call imp%get_pointer(b3, trim(base), r)
-                  a3 = b3 * 0.99
-               end if
-            end do
-         end associate
+      do cc = 1, size(gcs)
+         do ii = 1, gim(cc)%p%n
+            name = gim(cc)%p%f(ii)%name
+            n = len_trim(name)
+            if (n <= 6) cycle
+            if (name(n-5:n) /= '_avg24') cycle
+            base = name(1:n-6)
+            if (esmfl_state_index(gim(cc), trim(base)) == 0) cycle
+            if (gim(cc)%p%f(ii)%ungridded > 0) then
+               call MAPL_GetPointer(gim(cc), a4, trim(name), rc=r)
+               call MAPL_GetPointer(gim(cc), b4, trim(base), rc=r)
+               a4 = b4 * 0.99
+            else
+               call MAPL_GetPointer(gim(cc), a3, trim(name), rc=r)
+               call MAPL_GetPointer(gim(cc), b3, trim(base), rc=r)
+               a3 = b3 * 0.99
+            end if
+         end do
       end do
    end subroutine
 

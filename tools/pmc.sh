@@ -19,9 +19,8 @@ import csv, glob, collections, re, sys
 O, steps, want = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 tot = collections.defaultdict(float); cnt = collections.defaultdict(int)
 def short(name):
-    name = re.sub(r"^void ", "", name)
-    name = re.sub(r"\(.*$", "", name)
-    return name.replace("ohx::(anonymous namespace)::", "")
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    return re.sub(r"\(.*$", "", name)
 for f in glob.glob(O + '/*/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         if want in r['Kernel_Name']:
