@@ -144,7 +144,11 @@ int OHXDMatrixGetGrid(DMatrixHandle handle, int* im, int* jm, bst_ulong* row0, i
 /* The same search on demand.  Waits for `stream` (the rows must be there), then looks; *found (may be
  * NULL) says whether a level size was found.  Replaces any earlier hint.  A device-resident caller that
  * wants OHXBoosterPredictDevice never to wait calls this (or OHXDMatrixSetGrid) beforehand: the first
- * predict on a matrix nobody has described waits for its stream once to look. */
+ * predict on a matrix nobody has described waits for its stream once to look.  For matrices the library copied
+ * itself (XGDMatrixCreateFromMat) that is once per SHAPE: what the first predict finds is remembered by (rows,
+ * columns) for the life of the process, so a host that creates and frees its matrix every tick, as the reference
+ * does (OH_GridCompMod.F90:347,377), pays the search and the wait at the first tick only.  This call and
+ * OHXDMatrixGetGrid always look. */
 int OHXDMatrixInferGrid(DMatrixHandle handle, void* stream, int* found);
 
 /* Predict straight into device memory: d_out[nrow] margins (or [nrow][ntree]
@@ -275,13 +279,18 @@ int OHXBoosterKernelSymbol(BoosterHandle handle, bst_ulong ncol, const char** ou
  * d_full on every rank.  Set-up as RCCL's own: rank 0 calls OHXCommGetUniqueId, the host distributes the
  * OHX_UNIQUE_ID_BYTES bytes by whatever it has (MPI_Bcast in a GEOS-like host), every rank - its HIP device
  * already current - calls OHXCommInitRank.  OHXAllGatherOH only enqueues on `stream`; d_shard may be
- * d_full + row0 (in place).  Equal shards are one ncclAllGather; ragged ones one group of broadcasts.
- * librccl.so is loaded at the first of these calls, not linked. */
+ * d_full + row0 (in place).  Equal shards are one ncclAllGather; ragged ones - and equal ones when the
+ * environment says OHX_ALLGATHER=pairs - the direct exchange of SURVEY.md §8e: one group of ncclSend / ncclRecv
+ * between all pairs of ranks, every shard travelling its own xGMI link.  The communicator belongs to the HIP
+ * device that was current at OHXCommInitRank: a call with another device current is refused.
+ * librccl.so is loaded at the first of these calls, not linked (nor is its header needed to build). */
 typedef void* OHXCommHandle;
 #define OHX_UNIQUE_ID_BYTES 128
 int OHXCommGetUniqueId(void* id);
 int OHXCommInitRank(const void* id, int nranks, int rank, OHXCommHandle* out);
 int OHXCommFree(OHXCommHandle comm);
+/* RCCL's version code (ncclGetVersion), for a benchmark's record */
+int OHXCommInfo(int* rccl_version);
 /* rows [*row0, *row0 + *nrows) of rank `rank`: contiguous, sizes differing by at most one row */
 int OHXShardRows(bst_ulong nrows_total, int nranks, int rank, bst_ulong* row0, bst_ulong* nrows);
 int OHXAllGatherOH(OHXCommHandle comm, const float* d_shard, bst_ulong nrows_local, bst_ulong nrows_total,

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXDMatrixInferGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device", "OHXOHPostProcess", "OHXOHPostProcessDevice",
     "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXBoosterKernelSymbol", "OHXReleaseScratch",
-    "OHXCommGetUniqueId", "OHXCommInitRank", "OHXCommFree", "OHXShardRows", "OHXAllGatherOH",
+    "OHXCommGetUniqueId", "OHXCommInitRank", "OHXCommFree", "OHXCommInfo", "OHXShardRows", "OHXAllGatherOH",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
 REFERENCE_BOUND_SYMBOLS = [
@@ -121,6 +121,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.OHXCommGetUniqueId.argtypes = [vp]
     lib.OHXCommInitRank.argtypes = [vp, i32, i32, C.POINTER(vp)]
     lib.OHXCommFree.argtypes = [vp]
+    lib.OHXCommInfo.argtypes = [C.POINTER(i32)]
     lib.OHXShardRows.argtypes = [u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
     lib.OHXAllGatherOH.argtypes = [vp, vp, u64, u64, vp, vp]
     if path == LIB_PATH:
@@ -413,6 +414,14 @@ class Communicator:
         buf = C.create_string_buffer(UNIQUE_ID_BYTES)
         check(lib, lib.OHXCommGetUniqueId(C.cast(buf, C.c_void_p)))
         return buf.raw
+
+    @staticmethod
+    def rccl_version(lib: Optional[C.CDLL] = None) -> int:
+        """ncclGetVersion's code of the librccl.so the library loaded (e.g. 22705 for 2.27.5)."""
+        lib = lib or load_library()
+        v = C.c_int()
+        check(lib, lib.OHXCommInfo(C.byref(v)))
+        return v.value
 
     def all_gather_oh(self, shard_ptr: int, n_local: int, n_total: int, full_ptr: int, stream: int = 0) -> None:
         check(self.lib, self.lib.OHXAllGatherOH(self.handle, shard_ptr, n_local, n_total, full_ptr, stream or None))

@@ -238,7 +238,16 @@ struct CheckScratch {
 CheckScratch g_check;
 
 struct DMatrixObj {
-  ~DMatrixObj() { g_row_pool.give(owned, owned_cap, device); }
+  ~DMatrixObj() {
+    // XGBoosterPredict has waited for its kernels; OHXBoosterPredictDevice only enqueues, and the next
+    // XGDMatrixCreateFromMat copies into a parked buffer on the null stream: not before the readers are done
+    if (owned != nullptr && used_async) {
+      (void)hipSetDevice(device);
+      (void)hipDeviceSynchronize();
+    }
+    g_row_pool.give(owned, owned_cap, device);
+  }
+  bool used_async = false;
   uint64_t nrow = 0, ncol = 0;
   float missing = NAN;
   const float* d_data = nullptr;  // device
@@ -261,6 +270,7 @@ struct BoosterObj {
     if (train.side) (void)hipStreamDestroy(train.side);
     if (train.fork) (void)hipEventDestroy(train.fork);
     if (train.join) (void)hipEventDestroy(train.join);
+    if (cluster_done) (void)hipEventDestroy(cluster_done);
   }
   TrainStreams train;              // second stream of the launch train (kernels.hpp), made at upload
   Forest forest;
@@ -300,6 +310,10 @@ struct BoosterObj {
   DevBuf<uint32_t> d_cluster_keys[2], d_cluster_vals[2], d_cluster_small;
   DevBuf<uint8_t> d_cluster_temp;
   PinnedBuf<uint32_t> h_cluster_small;
+  // the walk that reads the permutation out of the buffers above is asynchronous: recorded behind it, waited for by
+  // the next clustering pass on this booster whatever stream that one runs on
+  hipEvent_t cluster_done = nullptr;
+  bool cluster_in_flight = false;
   std::vector<DevBuf<float>> d_run1_stage;
 };
 
@@ -524,19 +538,66 @@ void adopt_level_size(DMatrixObj& d, const uint32_t* verdict, uint32_t kmax) {
     }
 }
 
-// Launches + one read-back on `stream`; waits for it (the rows must be there).
-void infer_level_size(DMatrixObj& d, hipStream_t stream) {
+// What the search found for matrices of a shape seen before.  The reference creates and frees its DMatrix on every
+// OH tick (OH_GridCompMod.F90:347,377) with the same N x 27 every time: the launches and the host wait of the search
+// are paid at the first tick only.  Speed only - any period is a valid tiling of the rows - so a later matrix of the
+// same shape from another grid is tiled with the remembered level size, not wrongly.  OHXDMatrixInferGrid always looks.
+struct LevelSizeCache {
+  std::mutex mu;
+  struct Entry {
+    uint64_t nrow, ncol;
+    int period;      // 0 = looked and found none
+  };
+  std::vector<Entry> seen;
+  bool find(uint64_t nrow, uint64_t ncol, int* period) {
+    std::lock_guard<std::mutex> g(mu);
+    for (const Entry& e : seen)
+      if (e.nrow == nrow && e.ncol == ncol) {
+        *period = e.period;
+        return true;
+      }
+    return false;
+  }
+  void put(uint64_t nrow, uint64_t ncol, int period) {
+    std::lock_guard<std::mutex> g(mu);
+    for (Entry& e : seen)
+      if (e.nrow == nrow && e.ncol == ncol) {
+        e.period = period;
+        return;
+      }
+    if (seen.size() >= 64) seen.erase(seen.begin());
+    seen.push_back({nrow, ncol, period});
+  }
+};
+LevelSizeCache g_level_sizes;
+
+// Launches + one read-back on `stream`; waits for it (the rows must be there) - unless a matrix of this shape has
+// been searched before and `use_cache` allows taking its verdict.
+void infer_level_size(DMatrixObj& d, hipStream_t stream, bool use_cache = false) {
   d.grid_looked = true;
   const uint32_t kmax = level_candidates(d);
   if (kmax < 2) return;
-  std::lock_guard<std::mutex> g(g_check.mu);
-  const size_t words = (size_t)4 * (kmax - 1);
-  g_check.ensure(words, d.device);
-  HIP_CHECK(hipMemsetAsync(g_check.d.p, 0, words * sizeof(uint32_t), stream));
-  HIP_CHECK(launch_detect_period(d.d_data, d.nrow, (uint32_t)d.ncol, level_columns(d), 4, kmax, g_check.d.p, stream));
-  HIP_CHECK(hipMemcpyAsync(g_check.h.p, g_check.d.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  HIP_CHECK(hipStreamSynchronize(stream));
-  adopt_level_size(d, g_check.h.p, kmax);
+  int period = 0;
+  if (use_cache && g_level_sizes.find(d.nrow, d.ncol, &period)) {
+    if (period > 0) {
+      d.grid_im = period;
+      d.grid_jm = 1;
+      d.grid_row0 = 0;
+      d.grid_inferred = true;
+    }
+    return;
+  }
+  {
+    std::lock_guard<std::mutex> g(g_check.mu);
+    const size_t words = (size_t)4 * (kmax - 1);
+    g_check.ensure(words, d.device);
+    HIP_CHECK(hipMemsetAsync(g_check.d.p, 0, words * sizeof(uint32_t), stream));
+    HIP_CHECK(launch_detect_period(d.d_data, d.nrow, (uint32_t)d.ncol, level_columns(d), 4, kmax, g_check.d.p, stream));
+    HIP_CHECK(hipMemcpyAsync(g_check.h.p, g_check.d.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    adopt_level_size(d, g_check.h.p, kmax);
+  }
+  g_level_sizes.put(d.nrow, d.ncol, d.grid_inferred ? d.grid_im : 0);
 }
 
 // Rows nobody has described and in which no level size was found: group them by the decisions they take at
@@ -561,6 +622,9 @@ const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a,
   while (cluster_key_bits(c) > 32u && c.nsteps > 1) --c.nsteps;
   while (cluster_key_bits(c) > 32u && c.ntrees > 1) --c.ntrees;
   const unsigned sort_bits = cluster_key_bits(c);
+  // an earlier walk of this booster may still be reading its permutation out of these buffers (another stream,
+  // another matrix): the keys of this pass go in behind it
+  if (b.cluster_in_flight) HIP_CHECK(hipStreamWaitEvent(stream, b.cluster_done, 0));
   for (int q = 0; q < 2; ++q) {
     b.d_cluster_keys[q].ensure(d.nrow);
     b.d_cluster_vals[q].ensure(d.nrow);
@@ -611,7 +675,9 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
                    std::to_string(b.dev.ordinal));
   KernelKind kind = pick_kernel(b);
   // nobody has said which grid the rows come from: look once (work on `stream` enqueued so far is waited for)
-  if (!d.grid_looked && d.grid_im == 0 && !pred_leaf && kind != KernelKind::Wide) infer_level_size(d, stream);
+  // (a matrix the library copied itself - the reference's create / predict / free per tick - takes the verdict of
+  // the last matrix of its shape instead of looking again)
+  if (!d.grid_looked && d.grid_im == 0 && !pred_leaf && kind != KernelKind::Wide) infer_level_size(d, stream, d.owned != nullptr);
   if (pred_leaf || kind == KernelKind::Wide) ensure_wide(b);
   PredictArgs a;
   a.rows = d.d_data;
@@ -628,6 +694,11 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
   tune.grid_row0 = d.grid_row0;
   a.perm = cluster_rows(b, d, a, pred_leaf, kind, stream);
   HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, tune));
+  if (a.perm != nullptr) {
+    if (b.cluster_done == nullptr) HIP_CHECK(hipEventCreateWithFlags(&b.cluster_done, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(b.cluster_done, stream));
+    b.cluster_in_flight = true;
+  }
 }
 
 }  // namespace
@@ -988,6 +1059,7 @@ int OHXBoosterPredictDevice(BoosterHandle handle, DMatrixHandle dmat, int option
   BoosterObj* b = as_booster(handle);
   DMatrixObj* d = as_dmat(dmat);
   if (d_out == nullptr && d->nrow != 0) throw OhxError("OHXBoosterPredictDevice: d_out is NULL");
+  d->used_async = true;
   launch_predict_checked(*b, *d, option_mask, ntree_limit, d_out, static_cast<hipStream_t>(stream));
   API_END();
 }

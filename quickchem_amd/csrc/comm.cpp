@@ -7,12 +7,13 @@
 // broadcasts the 128-byte id of OHXCommGetUniqueId with its own MPI (that is all MPI is needed for), every
 // rank calls OHXCommInitRank, and OHXAllGatherOH enqueues the collective on the caller's stream.
 //
-// RCCL is loaded at the first call (dlopen "librccl.so"), not linked: the single-GPU product has no use for it
-// and must load where it is absent.
+// RCCL is loaded at the first call (dlopen "librccl.so"), not linked, and its header is not needed to build: the
+// single-GPU product has no use for it and must build and load where it is absent.  The handful of types and
+// prototypes used are declared below as RCCL's ABI has them (nccl.h: ncclUniqueId is 128 bytes, ncclFloat is 7).
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -29,16 +30,26 @@ void set_last_error(const std::string& m);   // capi.cpp: the per-thread text be
 
 namespace {
 
+// RCCL's C ABI, as far as it is used here
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+typedef int ncclDataType_t;
+constexpr ncclDataType_t ncclFloat = 7;
+
 struct Rccl {
   void* so = nullptr;
-  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-  decltype(&ncclCommInitRank) CommInitRank = nullptr;
-  decltype(&ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&ncclAllGather) AllGather = nullptr;
-  decltype(&ncclBroadcast) Broadcast = nullptr;
-  decltype(&ncclGroupStart) GroupStart = nullptr;
-  decltype(&ncclGroupEnd) GroupEnd = nullptr;
-  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 
 Rccl& rccl() {
@@ -61,12 +72,14 @@ Rccl& rccl() {
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
-    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
   });
-  if (!r.so || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.Broadcast || !r.GroupStart ||
+  if (!r.so || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart ||
       !r.GroupEnd || !r.GetErrorString)
     throw OhxError("RCCL is not usable here (the multi-GPU all-gather needs librccl.so): " + why);
   return r;
@@ -84,10 +97,36 @@ struct CommObj {
 std::mutex g_mu;
 std::unordered_set<const void*> g_live;
 
-CommObj* as_comm(OHXCommHandle h) {
-  std::lock_guard<std::mutex> g(g_mu);
+// A handle is checked against the table of live communicators, never by reading the object.  The lock is held by
+// the caller for as long as the object is used (a collective is only enqueued under it): a free on another thread
+// cannot pull the communicator away from under a call.
+CommObj* as_comm_locked(OHXCommHandle h) {
   if (h == nullptr || !g_live.count(h)) throw OhxError("communicator handle is invalid or has been freed");
   return static_cast<CommObj*>(h);
+}
+
+// closes an open RCCL group on every way out, the throwing ones included
+struct GroupGuard {
+  Rccl& r;
+  bool open = false;
+  explicit GroupGuard(Rccl& rr) : r(rr) {}
+  void start() {
+    nccl_check(r.GroupStart(), "ncclGroupStart");
+    open = true;
+  }
+  void end() {
+    open = false;
+    nccl_check(r.GroupEnd(), "ncclGroupEnd");
+  }
+  ~GroupGuard() {
+    if (open) (void)r.GroupEnd();
+  }
+};
+
+// OHX_ALLGATHER=pairs asks for the direct exchange also where the shards are equal (default: ncclAllGather there)
+bool pairs_wanted() {
+  const char* e = getenv("OHX_ALLGATHER");
+  return e != nullptr && strcmp(e, "pairs") == 0;
 }
 
 #define COMM_API_BEGIN() try {
@@ -144,14 +183,23 @@ int OHXCommInitRank(const void* id, int nranks, int rank, OHXCommHandle* out) {
 
 int OHXCommFree(OHXCommHandle handle) {
   COMM_API_BEGIN();
-  CommObj* c = as_comm(handle);
+  CommObj* c = nullptr;
   {
-    std::lock_guard<std::mutex> g(g_mu);
+    std::lock_guard<std::mutex> g(g_mu);            // look-up and erase in one step: of two frees one fails
+    c = as_comm_locked(handle);
     g_live.erase(handle);
   }
   ncclResult_t rc = rccl().CommDestroy(c->comm);
   delete c;
   nccl_check(rc, "ncclCommDestroy");
+  COMM_API_END();
+}
+
+int OHXCommInfo(int* rccl_version) {
+  COMM_API_BEGIN();
+  int v = 0;
+  nccl_check(rccl().GetVersion ? rccl().GetVersion(&v) : ncclSuccess, "ncclGetVersion");
+  if (rccl_version) *rccl_version = v;
   COMM_API_END();
 }
 
@@ -167,7 +215,12 @@ int OHXShardRows(bst_ulong nrows_total, int nranks, int rank, bst_ulong* row0, b
 int OHXAllGatherOH(OHXCommHandle handle, const float* d_shard, bst_ulong nrows_local, bst_ulong nrows_total,
                    float* d_full, void* stream) {
   COMM_API_BEGIN();
-  CommObj* c = as_comm(handle);
+  std::lock_guard<std::mutex> g(g_mu);
+  CommObj* c = as_comm_locked(handle);
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != c->device)
+    throw OhxError("OHXAllGatherOH: the communicator was made on HIP device " + std::to_string(c->device) +
+                   " but the current device is " + std::to_string(dev));
   bst_ulong row0 = 0, mine = 0;
   (void)OHXShardRows(nrows_total, c->nranks, c->rank, &row0, &mine);
   if (mine != nrows_local)
@@ -178,20 +231,27 @@ int OHXAllGatherOH(OHXCommHandle handle, const float* d_shard, bst_ulong nrows_l
   if (d_full == nullptr || (d_shard == nullptr && nrows_local != 0)) throw OhxError("OHXAllGatherOH: NULL buffer");
   hipStream_t s = static_cast<hipStream_t>(stream);
   Rccl& r = rccl();
-  if (nrows_total % (bst_ulong)c->nranks == 0) {
+  if (nrows_total % (bst_ulong)c->nranks == 0 && !pairs_wanted()) {
     // equal shards: one all-gather, straight into place (in place when d_shard already is d_full + row0)
     nccl_check(r.AllGather(d_shard, d_full, (size_t)nrows_local, ncclFloat, c->comm, s), "ncclAllGather");
   } else {
-    // ragged shards: every rank broadcasts its own piece to its rows, as one group
-    nccl_check(r.GroupStart(), "ncclGroupStart");
+    // The direct exchange: every rank sends its shard to every peer and receives every peer's shard
+    // at its rows, all of it one group - on the node's full xGMI mesh each pair has a link of its own, where a ring
+    // is bound by one link per step.  Shards need not be equal.  The rank's own rows are a device copy.
+    if (d_shard != d_full + row0 && nrows_local != 0) {
+      hipError_t e = hipMemcpyAsync(d_full + row0, d_shard, (size_t)nrows_local * sizeof(float), hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) throw OhxError(std::string("OHXAllGatherOH: hipMemcpyAsync failed: ") + hipGetErrorString(e));
+    }
+    GroupGuard group(r);
+    group.start();
     for (int q = 0; q < c->nranks; ++q) {
+      if (q == c->rank) continue;
       bst_ulong r0 = 0, n = 0;
       (void)OHXShardRows(nrows_total, c->nranks, q, &r0, &n);
-      if (n == 0) continue;
-      nccl_check(r.Broadcast(q == c->rank ? (const void*)d_shard : (const void*)(d_full + r0), d_full + r0, (size_t)n,
-                             ncclFloat, q, c->comm, s), "ncclBroadcast");
+      if (nrows_local != 0) nccl_check(r.Send(d_shard, (size_t)nrows_local, ncclFloat, q, c->comm, s), "ncclSend");
+      if (n != 0) nccl_check(r.Recv(d_full + r0, (size_t)n, ncclFloat, q, c->comm, s), "ncclRecv");
     }
-    nccl_check(r.GroupEnd(), "ncclGroupEnd");
+    group.end();
   }
   COMM_API_END();
 }

@@ -353,6 +353,40 @@ def test_month_roll_over_by_name_on_the_gpu(torch_cuda, tmp_path, small_model):
             assert helpers.ulp_diff(oh_g[:, :, k1 - 1:], oh_c[:, :, k1 - 1:]).max() <= 2
 
 
+def test_inferred_level_size_that_is_not_a_multiple_of_four(torch_cuda, small_model):
+    """A level of 97 x 71 = 6 887 cells: the runs of rows a wave fetches together (load_pieces) then start at
+    addresses that are 4-byte but not 16-byte aligned, with the level size found by the library itself - through
+    the compat calls (the verdict of the first tick serves the later ones) and on a device-resident matrix."""
+    grid = (97, 71, 72)
+    rows = synth.rows_cpu(grid, 0, 97 * 71 * 9)
+    want = helpers.oracle_predict(small_model.image, rows, synth.XX_MISS)
+    b = capi.Booster(model_buffer=small_model.image)
+    for tick in range(3):                                  # create / predict / free, as the reference does every tick
+        d = capi.DMatrix(rows, missing=synth.XX_MISS)
+        assert np.array_equal(helpers.bits(b.predict(d)), helpers.bits(want)), tick
+        assert d.grid() == (97 * 71, 1, 0, True)
+        d.free()
+    # rows of the same shape that are NOT level-stacked, after the library has seen that shape: still right
+    shuffled = rows[np.random.default_rng(5).permutation(len(rows))]
+    d = capi.DMatrix(shuffled, missing=synth.XX_MISS)
+    assert np.array_equal(helpers.bits(b.predict(d)),
+                          helpers.bits(helpers.oracle_predict(small_model.image, shuffled, synth.XX_MISS)))
+    d.free()
+    t = torch_cuda.from_numpy(rows).cuda()
+    out = torch_cuda.empty(rows.shape[0], dtype=torch_cuda.float32, device="cuda")
+    for hint in ("none", "full"):
+        dd = capi.DMatrix(device_ptr=t.data_ptr(), nrow=rows.shape[0], ncol=27, missing=synth.XX_MISS)
+        if hint == "full":
+            dd.set_grid(97, 71, 0)
+        out.zero_()
+        b.predict_device(dd, out.data_ptr())
+        torch_cuda.cuda.synchronize()
+        b.check()
+        assert np.array_equal(helpers.bits(out.cpu().numpy()), helpers.bits(want)), hint
+        dd.free()
+    assert b.lib.OHXReleaseScratch() == 0
+
+
 def test_level_size_is_inferred_from_the_rows(torch_cuda, small_model):
     """No hint: XGDMatrixCreateFromMat finds the level size of a level-stacked gather from the exact
     repetition of its first column (LAT) and tiles by it; predictions are the same bit for bit.  An explicit
