@@ -179,9 +179,6 @@ __device__ __forceinline__ bool store_row27(float* __restrict__ tile, const Row2
 //   row r of run g belongs to lane  lane_of(g) | r << run_lo_bits
 // (level-fastest bricks: run_lo_bits = lk; i-fastest and gridless tiles: 0.)
 constexpr uint32_t kPiecesPerTile = kWave * 27u / 4u;   // 432
-// which of the 27 OH features are 2-D fields, and which one is a pressure in Pa (OH_GridCompMod.F90:313-339)
-constexpr uint32_t kOhIs2dMask = (1u << 0) | (1u << 21) | (1u << 22) | (1u << 26);
-constexpr uint32_t kOhPlFeature = 1u;
 
 __device__ __forceinline__ uint32_t div27(uint32_t x) { return (x * 1214u) >> 15; }   // exact below 1728
 
@@ -663,8 +660,7 @@ __global__ __launch_bounds__(kBlock) void predict_rows_direct_kernel(DeviceFores
 // applies PL/100 (OH_GridCompMod.F90:314), walks, writes 10**pred * OHscale
 // (OH_GridCompMod.F90:369,1569) into OH_ML(i,j,k1..k2).
 template <int FMT, int CHAINS, bool TOPS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS > 3 ? 4 : 5))) void predict_fields_kernel(
-    DeviceForest fr, FieldsArgs a, const SuperTreeHead* __restrict__ heads,
+__global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr, FieldsArgs a, const SuperTreeHead* __restrict__ heads,
                                                                 float* __restrict__ out,
                                                                 float* __restrict__ margin_out) {
   extern __shared__ float lds[];
@@ -689,28 +685,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
     const uint64_t m = tile_row(a.shape, tile_id, lane, nrow, &valid);
     const uint64_t col = valid ? m % plane : 0;
     bool lane_nan = false, any_inf = false;
-    if (fr.num_feature == 27u && a.nfield == 27u && a.is2d_mask == kOhIs2dMask && a.pl_feature == kOhPlFeature) {
-      // The OH gather itself (OH_GridCompMod.F90:313-339: LAT, GMISTRATO3, ALBUV and SZA are 2-D, PL is divided by
-      // 100), everything known at compile time: all 27 loads are issued before the first value is looked at.  As a
-      // loop over a run-time field count the fill was 27 loads one after the other, each waited for before the next
-      // was issued - 27 memory latencies per tile, a tenth of a tile's time (profiles/r03_sweeps.txt).
-      float v[27];
-      const uint64_t at3 = valid ? slab + m : 0;
-#pragma unroll
-      for (int f = 0; f < 27; ++f)
-        v[f] = __builtin_nontemporal_load(a.field[f] + (((kOhIs2dMask >> f) & 1u) ? col : at3));
-#pragma unroll
-      for (int f = 0; f < 27; ++f) {
-        float x = v[f];
-        if (f == (int)kOhPlFeature) x = x / 100.0f;                 // :314
-        any_inf |= is_inf(x);
-        if (!missing_is_nan && x == a.missing) x = qnan;
-        if (!valid) x = 0.0f;
-        lane_nan |= (x != x);
-        tile[f * kWave] = x;
-      }
-      any_inf = any_inf && valid;
-    } else
+    // The fields come one after the other, each load waited for before the next is issued.  Issuing the OH gather's
+    // 27 loads together (a compile-time unrolled fill) is SLOWER: 35.2 against 33.6 ms per C360 step - a burst of 27
+    // four-byte gathers from one wave stands in front of the other waves' node gathers at the texture addresser,
+    // which a walk that is bound there feels more than this wave feels its own latency (profiles/r03_sweeps.txt).
     for (uint32_t f = 0; f < fr.num_feature; ++f) {
       float x = qnan;
       if (valid && f < a.nfield) {
