@@ -54,7 +54,8 @@ def parse_args():
     ap.add_argument("--line-slots", type=int, default=None)
     ap.add_argument("--param", action="append", default=[], help="extra XGBoosterSetParam name=value (repeatable)")
     ap.add_argument("--missing-ppm", type=int, default=0, help="inject -999.0/NaN at this rate per million entries")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="cpu_baseline leg: 0 = skip, < 10 = a one-level sample, else the fixed sample (8 levels, 3 ticks)")
     ap.add_argument("--shuffle", action="store_true", help="permute the rows (destroys spatial coherence)")
     ap.add_argument("--infer-grid", action="store_true",
                     help="rows path: no hint either, but let the library look for the level size in the rows "
@@ -71,9 +72,12 @@ def parse_args():
     ap.add_argument("--gather-chunks", type=int, default=4,
                     help="N > 1: cut the shard into this many pieces so that a piece's all-gather overlaps the next "
                          "piece's prediction (1 = predict everything, then one all-gather)")
-    ap.add_argument("--gather", default="torch", choices=["torch", "native"],
-                    help="N > 1: the all-gather through torch.distributed (RCCL process group), or through the C ABI's "
-                         "own OHXAllGatherOH (what a Fortran/MPI host would call)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "native", "none"],
+                    help="N > 1: the all-gather through torch.distributed (RCCL process group), through the C ABI's "
+                         "own OHXAllGatherOH (what a Fortran/MPI host would call), or not at all (a control: predict "
+                         "only, so that a weak scaling curve can be split into prediction and exchange; not a result)")
+    ap.add_argument("--rows", type=int, default=0,
+                    help="use only the first N rows of the grid's batch (tests of ragged shards: N % gpus != 0)")
     ap.add_argument("--path", default="rows", choices=["rows", "fields", "run1"],
                     help="rows: AoS xx_carr -> margins (the headline); fields: the fused SoA call, 27 MAPL fields -> "
                          "10**pred*OHscale; run1: OHXBoosterRun1Device, imports -> INTERNAL OH (both 1 GPU only)")
@@ -103,11 +107,13 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def fortran_cpu_leg(model_image, grid, fields, levels, threads, workdir):
+def fortran_cpu_leg(model_image, grid, fields, levels, threads, workdir, ncalls):
     """oracle/lib/oh_mock_driver_oracle on the first `levels` levels of the batch's MAPL fields: the Fortran host's
-    predict_OH_with_XGB (gather + XGDMatrixCreateFromMat + XGBoosterPredict + 10**) over the oracle library.
-    `fields` = the 27 fields in HBM (torch tensors, Fortran order).  Returns (gridcells per second,
-    OH_ML[levels*plane] in row order, seconds)."""
+    predict_OH_with_XGB (gather + XGDMatrixCreateFromMat + XGBoosterPredict + 10**) over the oracle library, `ncalls`
+    ticks in one process.  The first tick holds what the reference pays once per run (the model file is loaded at
+    the first call, OH_GridCompMod.F90:242-271; OpenMP team start-up, first touch of the buffers); the later ones are
+    what it pays per OH alarm tick (:308-374).  `fields` = the 27 fields in HBM (torch tensors, Fortran order).
+    Returns (OH_ML[levels*plane] in row order, seconds of every call)."""
     import struct
     import subprocess
     from quickchem_amd import synth
@@ -126,26 +132,31 @@ def fortran_cpu_leg(model_image, grid, fields, levels, threads, workdir):
         open(model, "wb").write(bytes(model_image))
     out = os.path.join(workdir, f"out_L{levels}_T{threads}.bin")
     exe = os.path.join(ROOT, "oracle", "lib", "oh_mock_driver_oracle")
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
-    r = subprocess.run([exe, state, model, out, "compat", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                       env=env)
+    # threads pinned and spread over the cores: unpinned teams gave 0.89 / 0.94 / 1.04 M gridcells/s in three runs
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="spread", OMP_PLACES="cores")
+    r = subprocess.run([exe, state, model, out, "compat", str(ncalls)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, env=env)
     if r.returncode != 0:
         raise SystemExit(f"bench: the Fortran CPU leg failed: {r.stdout[-500:]}")
     raw = open(out, "rb").read()
     rc, k1, k2 = struct.unpack_from("<iii", raw, 0)
     n = plane * levels
     oh = np.frombuffer(raw, dtype="<f4", count=n, offset=12)
-    (seconds,) = struct.unpack_from("<d", raw, 12 + 4 * n)
     if rc != 0 or (k1, k2) != (1, levels):
         raise SystemExit(f"bench: the Fortran CPU leg returned rc={rc}, slab {k1}..{k2}")
+    times = [float(x) for x in open(out + ".times").read().split()]
     os.remove(out)
-    return n / seconds, oh, seconds
+    os.remove(out + ".times")
+    return oh, times
 
 
 def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
     """The reference-equivalent CPU path next to the GPU number: Fortran host + oracle, one
     thread and all host cores, on the first levels of the batch's 27 MAPL fields; its OH_ML is compared with the
-    GPU's fused call on the same fields.  A real libxgboost, if this machine has one, is timed and compared as well."""
+    GPU's fused call on the same fields.  `value` is a STEADY-STATE tick (the fastest of the ticks after the first,
+    all in one process); the first tick and the one-time share of it are reported beside it.  The sample is fixed:
+    8 levels at all cores (3 ticks), 1 level at one thread (2 ticks) - a shorter one only for a small budget.
+    A real libxgboost, if this machine has one, is timed and compared as well."""
     import shutil
     import tempfile
     from quickchem_amd import capi, synth
@@ -158,19 +169,16 @@ def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
         t = torch.empty(plane * (1 if synth.IS2D[feat] else km), dtype=torch.float32, device=dev)
         synth.field_device(grid, feat, t)
         fields.append(t)
+    full = budget_s >= 10
+    levels = min(km, 8) if full else 1
     workdir = tempfile.mkdtemp(prefix="ohx_cpu_leg_")
     try:
-        # one level: the one-thread figure and the probe for the all-cores sample
-        r1, oh1, t1 = fortran_cpu_leg(model_image, grid, fields, 1, 1, workdir)
-        rp, _, tp = fortran_cpu_leg(model_image, grid, fields, 1, cores, workdir)
-        levels = int(max(1, min(km, 24, (0.6 * budget_s * rp) // plane)))
-        if levels > 1:
-            rate, oh, secs = fortran_cpu_leg(model_image, grid, fields, levels, cores, workdir)
-        else:
-            rate, oh, secs = rp, oh1, tp
+        oh1, t_one = fortran_cpu_leg(model_image, grid, fields, 1, 1, workdir, 2)
+        oh, t_all = fortran_cpu_leg(model_image, grid, fields, levels, cores, workdir, 3 if full else 2)
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
     n = plane * levels
+    steady, steady_one = min(t_all[1:]), min(t_one[1:])
     # the checker's verdict: the same fields through the GPU's fused call (gather, PL/100, walk, 10**) vs the
     # Fortran host + oracle; 10.0**x is libm-specific, hence 2 ulp (the raw margins are compared bit for bit below)
     oh_gpu = torch.zeros(plane * km, dtype=torch.float32, device=dev)
@@ -184,15 +192,23 @@ def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
     if ulp > 2:
         raise SystemExit(f"bench: GPU OH differs from the Fortran CPU path by {ulp} ulp on the cpu_baseline sample")
     del fields, oh_gpu
-    base = {"value": rate, "unit": "gridcells/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+    base = {"value": n / steady, "unit": "gridcells/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
             "sample": f"first {levels} of {km} levels ({n} gridcells) of the batch: oracle/lib/oh_mock_driver_oracle = the "
                       f"Fortran host's predict_OH_with_XGB (SoA->AoS gather, XGDMatrixCreateFromMat, XGBoosterPredict, "
                       f"10**pred; OH_GridCompMod.F90:308-374) linked against oracle/xgb_oracle.c, OMP_NUM_THREADS={cores} "
-                      f"(gather and 10** single-threaded as in the reference), {secs:.2f} s; libxgboost 1.6.0 itself is "
-                      f"not available here",
+                      f"pinned (OMP_PROC_BIND=spread OMP_PLACES=cores; gather and 10** single-threaded as in the "
+                      f"reference); {len(t_all)} ticks in one process, value = the fastest tick after the first "
+                      f"({steady:.2f} s); libxgboost 1.6.0 itself is not available here",
+            "ticks_s": [round(t, 4) for t in t_all],
+            "first_tick_s": round(t_all[0], 4),
+            "load_s": round(max(t_all[0] - steady, 0.0), 4),
+            "load_s_is": "first tick minus a steady tick: the model file parse of the first call (OH_GridCompMod.F90:"
+                         "242-271), OpenMP team start-up, first touch",
             "oh_max_ulp_vs_gpu_fused_call": ulp,
-            "one_thread": {"value": r1, "unit": "gridcells/s", "cores": 1,
-                           "sample": f"first level ({plane} gridcells), same executable, OMP_NUM_THREADS=1, {t1:.2f} s"},
+            "one_thread": {"value": plane / steady_one, "unit": "gridcells/s", "cores": 1,
+                           "sample": f"first level ({plane} gridcells), same executable, OMP_NUM_THREADS=1, "
+                                     f"{len(t_one)} ticks, the fastest after the first ({steady_one:.2f} s)",
+                           "ticks_s": [round(t, 4) for t in t_one]},
             "libxgboost": None}
     # opportunistic: a real libxgboost on this machine
     try:
@@ -408,7 +424,30 @@ def main():
 
     grid = synth.GRIDS[args.grid]
     n_total = grid[0] * grid[1] * grid[2]
+    if args.rows:
+        n_total = min(n_total, args.rows)
     row0, n_local = shard.row_shard(n_total, world, rank)
+
+    # ---- what an 8-GPU run is diagnosed from afterwards: who ran where, over which RCCL ----
+    dist_info = None
+    if world > 1 or force_dist:
+        assert dist.get_world_size() == args.gpus or force_dist, (dist.get_world_size(), args.gpus)
+        ident = [None] * dist.get_world_size()
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device": dev_index, "host": os.uname().nodename,
+                "uuid": str(getattr(props, "uuid", "")), "name": props.name}
+        dist.all_gather_object(ident, mine)
+        places = {(i["host"], i["device"]) for i in ident}
+        if len(places) != len(ident) and os.environ.get("OHX_BENCH_SHARE_GPU") != "1":
+            raise SystemExit(f"bench: two ranks share a GPU: {ident}")
+        try:
+            rccl = capi.Communicator.rccl_version() if backend == "nccl" else None
+        except capi.OhxError:
+            rccl = None
+        dist_info = {"backend": backend, "world_size": dist.get_world_size(), "ranks": ident, "rccl_version": rccl,
+                     "torch_nccl_version": ".".join(map(str, torch.cuda.nccl.version())) if backend == "nccl" else None,
+                     "env": {k: os.environ[k] for k in sorted(os.environ)
+                             if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "OHX_ALLGATHER"))}}
 
     # ---- the booster: seeded synthetic OH model, identical on every rank ----
     synth.set_threads(max(1, (os.cpu_count() or 8) // max(world, 1)))
@@ -443,10 +482,10 @@ def main():
     torch.cuda.synchronize()
     out_local = torch.empty(n_local, dtype=torch.float32, device=dev)
     even = (n_total % world == 0)
-    # pieces of the shard: one DMatrix view each (device pointers into `rows`)
-    gather = world > 1 or force_dist
-    use_grid = not (args.no_grid or args.shuffle or args.infer_grid or args.consecutive)
     plane = grid[0] * grid[1]
+    # pieces of the shard: one DMatrix view each (device pointers into `rows`)
+    gather = (world > 1 or force_dist) and args.gather != "none"
+    use_grid = not (args.no_grid or args.shuffle or args.infer_grid or args.consecutive)
     # pieces are whole levels when the shard is (bricks then have no idle lanes), else whole launches
     granule = plane if (use_grid and row0 % plane == 0 and n_local % plane == 0) else 64 * 256 * 20 * 2
     round_rows = torch.cuda.get_device_properties(dev).multi_processor_count * 20 * 64   # one residency of the chip
@@ -494,7 +533,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if gather:
+        if world > 1 or force_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -583,8 +622,16 @@ def main():
                           "build_s": round(t_model, 2)},
                 "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid), "grid_known_to_library": list(dmats[0].grid()), "verified": verified,
                 "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
-                "gather_via": (args.gather if gather else None),
+                "gather_via": (args.gather if (world > 1 or force_dist) else None),
             },
+            # N > 1: where a step's time goes.  predict_ms = first launch to last launch of the rank's pieces (events
+            # on the launching stream, max over ranks); exposed_gather_ms = what the step takes beyond that: the part
+            # of the all-gather (and of the copies into place) that the prediction of the next piece does not hide
+            "phases": ({"predict_ms": kernel_s * 1e3, "exposed_gather_ms": ms_per_step - kernel_s * 1e3,
+                        "gather_bytes_per_rank_sent": 4 * n_local, "gather_bytes_total": 4 * n_total,
+                        "pieces": [hi - lo for lo, hi in pieces], "even_shards": even}
+                       if (world > 1 or force_dist) else None),
+            "distributed": dist_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -600,7 +647,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if gather:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -9,7 +9,8 @@
 !     real32 pl(im,jm,km)  tropp(im,jm)
 !     27 fields in the order of OH_GridCompMod.F90:313-339, (im,jm) for LAT,
 !     GMISTRATO3, ALBUV, SZA and (im,jm,km) for the others; PL in Pa
-!  out.bin: int32 rc, k1, k2; real32 OH_ML(im,jm,km); real64 seconds per call
+!  out.bin: int32 rc, k1, k2; real32 OH_ML(im,jm,km); real64 seconds per call (mean); int32 resident boosters
+!  out.bin.times (text): seconds of every call, one per line - the first holds the one-time model load (:242-271)
 program oh_mock_driver
    use, intrinsic :: iso_c_binding
    use oh_xgb_predict
@@ -22,8 +23,9 @@ program oh_mock_driver
    real, allocatable, target :: OH_ML(:,:,:)
    type(OH_BOOST_INPUT_DATA) :: bb
    integer :: rc, k1, k2, u, n2, n3, ncalls, it, rc2
-   integer(8) :: t0, t1, rate
+   integer(8) :: t0, t1, ta, tb, rate
    real(8) :: seconds
+   real(8), allocatable :: per_call(:)
    logical, parameter :: two_d(27) = [ .true., .false., .false., .false., .false., .false., .false., .false., .false., &
                                        .false., .false., .false., .false., .false., .false., .false., .false., .false., &
                                        .false., .false., .false., .true., .true., .false., .false., .false., .true. ]
@@ -101,8 +103,11 @@ program oh_mock_driver
    bb%CH2O       => f3(:,:,:,slot3(26))
    bb%SZA        => f2(:,:,slot2(27))
 
+   allocate(per_call(max(ncalls, 1)))
+   per_call = 0.0d0
    call system_clock(t0, rate)
    do it = 1, ncalls
+      call system_clock(ta)
       OH_ML(:,:,:) = 0.0                       ! OH_GridCompMod.F90:1559
       if (trim(mode) == 'fused') then
          call predict_OH_with_XGB_fused(oh_xgb_fill_template(model_file, 20240001 + 100*it, 0), im, jm, km, &
@@ -112,6 +117,8 @@ program oh_mock_driver
                                   dyn /= 0, tropp_min, pl, tropp, bb, OH_ML, rc)
          if (rc == OH_XGB_SUCCESS) OH_ML(:,:,:) = OH_ML(:,:,:) * ohscale      ! :1569
       end if
+      call system_clock(tb)
+      per_call(it) = real(tb - ta, 8) / real(rate, 8)
       if (rc /= OH_XGB_SUCCESS) exit
    end do
    call system_clock(t1)
@@ -130,6 +137,11 @@ program oh_mock_driver
    write(u) OH_ML
    write(u) seconds
    write(u) int(oh_xgb_resident_models(), c_int32_t)
+   close(u)
+   open(newunit=u, file=trim(out_file)//'.times', status='replace', action='write')
+   do it = 1, ncalls
+      write(u, '(es16.8)') per_call(it)
+   end do
    close(u)
    if (rc /= OH_XGB_SUCCESS) stop 1
 end program oh_mock_driver

@@ -161,6 +161,23 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(tmp_path):
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["config"]["verified"] is True and line["n_gpus"] == 2 and line["config"]["grid_hint"] is True
+        assert line["phases"]["even_shards"] is True and line["phases"]["gather_bytes_total"] == 4 * 90 * 540 * 72
+        assert line["phases"]["predict_ms"] > 0 and len(line["distributed"]["ranks"]) == 2
+    # ragged shards (an odd number of rows over two ranks: the fixed-slot gather and its compaction), and the
+    # predict-only control that a scaling curve is split with
+    for extra in (["--rows", "995327"], ["--gather", "none"]):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29578", os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--grid", "C48", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+                            "--verify"] + extra, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["config"]["verified"] is True and line["n_gpus"] == 2
+        if extra[0] == "--rows":
+            assert line["config"]["rows_total"] == 995327 and line["phases"]["even_shards"] is False
+            assert line["config"]["rows_per_gpu"] == 497664                      # rank 0 holds the odd row
+        else:
+            assert line["config"]["gather_pieces"] == 0 and line["config"]["gather_via"] == "none"
 
 
 def test_native_all_gather_entry_points_on_one_rank():
@@ -182,6 +199,17 @@ def test_native_all_gather_entry_points_on_one_rank():
     comm.all_gather_oh(full.data_ptr(), n, n, full.data_ptr())          # in place
     torch.cuda.synchronize()
     assert torch.equal(full, shard)
+    # the direct exchange (every shard to every peer as one group of sends and receives): with one rank its own
+    # rows are a device copy and the group is empty - the code path of ragged shards
+    os.environ["OHX_ALLGATHER"] = "pairs"
+    try:
+        full.zero_()
+        comm.all_gather_oh(shard.data_ptr(), n, n, full.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(full, shard)
+    finally:
+        del os.environ["OHX_ALLGATHER"]
+    assert capi.Communicator.rccl_version() >= 20000                     # ncclGetVersion of the library that was loaded
     with pytest.raises(capi.OhxError, match="holds 5 rows"):
         comm.all_gather_oh(shard.data_ptr(), 5, n, full.data_ptr())
     with pytest.raises(capi.OhxError, match="rank < nranks"):
