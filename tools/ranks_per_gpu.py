@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""How the reference really calls the path on a node: many MPI ranks, each with a small block in pageable host
+arrays, all sharing one GPU (OH_GridCompMod.F90:1199-1202: a rank predicts its own im x jm x km block; :305-383: the
+five calls per OH tick; NOTES.wiki:14,33: one rank per core).
+
+Starts P fresh processes on ONE GPU, P in --ranks.  Each is a "rank" that owns C360 / (8 P) gridcells (a
+(360, 2160 / (8 P), 72) sub-domain), loads the model FROM A FILE as a GEOS rank does (XGBoosterLoadModel), and runs
+--ticks ticks of
+   reference:  XGDMatrixCreateFromMat -> XGBoosterPredict -> XGDMatrixFree   (the booster made and loaded at the
+               first tick, as predict_OH_with_XGB does: :242-271), and
+   fused:      OHXBoosterPredictFields (gather, PL/100, walk, 10**, *OHscale in one call)
+from pageable numpy arrays.  The ranks start their ticks together (a start time handed to all of them).  Prints ONE JSON
+object: per P the aggregate gridcells/s over the common window, per-tick latency p50 / p95 / max, the first tick, and
+the HBM the processes hold together.
+
+The GPU boxes of this pool admit at most 6 processes on a card at once (gpurun's process guard), so P is taken from
+{1, 2, 3, 6}; the parent never touches the GPU.  usage (GPU box): python3 tools/ranks_per_gpu.py [--ranks 1,2,3,6]"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def hbm_free_bytes():
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    if hip.hipMemGetInfo(C.byref(free), C.byref(total)) != 0:
+        return None, None
+    return free.value, total.value
+
+
+def child(args):
+    from quickchem_amd import capi, synth
+    grid = synth.GRIDS[args.grid]
+    im, jm_all, km = grid
+    parts = 8 * args.nranks
+    jm = jm_all // parts
+    sub = (im, jm, km)
+    n = im * jm * km
+    # the rank's block, pageable host memory: the reference's xx_carr rows, and the same block as 27 SoA fields
+    # (a (360, jm, 72) sub-domain generated as a grid of its own, seeded by the rank)
+    seed = synth.FEATURE_SEED + args.rank
+    rows = synth.rows_cpu(sub, 0, n, seed=seed)
+    fields = [np.ascontiguousarray(synth.field_cpu(sub, f, seed=seed).T) for f in range(synth.NFEAT)]
+    oh = np.zeros(n, dtype=np.float32)
+    free0, total = None, None
+    out = {"rank": args.rank, "rows": n, "pid": os.getpid()}
+    while time.time() < args.start_at:
+        time.sleep(0.001)
+    t_begin = time.time()
+    free_before, total = hbm_free_bytes()                  # first HIP call of the process: context creation
+    out["hip_init_s"] = time.time() - t_begin
+    ticks = {"reference": [], "fused": []}
+    b = None
+    t_ref0 = time.time()
+    for tick in range(args.ticks):
+        t0 = time.perf_counter()
+        if b is None:                                      # first_time (:242-271): create + load, from the file
+            b = capi.Booster(args.model)
+        d = capi.DMatrix(rows, missing=synth.XX_MISS)
+        p = b.predict(d)
+        d.free()
+        ticks["reference"].append(time.perf_counter() - t0)
+    t_ref1 = time.time()
+    ref_sum = float(np.float64(p).sum())
+    for tick in range(args.ticks):
+        t0 = time.perf_counter()
+        b.predict_fields(fields, synth.IS2D, synth.PL_FEATURE, im, jm, km, 1, km, synth.XX_MISS, oh, ohscale=1.0,
+                         apply_pow10=False)
+        ticks["fused"].append(time.perf_counter() - t0)
+    t_fused1 = time.time()
+    free_after, _ = hbm_free_bytes()
+    same = bool(np.array_equal(oh.view(np.uint32), p.view(np.uint32)))      # both paths, same margins
+    out.update({"ticks_s": ticks, "window": {"reference": [t_ref0, t_ref1], "fused": [t_ref1, t_fused1]},
+                "paths_agree_bit_for_bit": same, "margin_sum": ref_sum,
+                "hbm_free_before": free_before, "hbm_free_after": free_after, "hbm_total": total})
+    print("RANK_JSON " + json.dumps(out), flush=True)
+    time.sleep(max(0.0, args.hold_until - time.time()))    # keep the memory until every rank has reported its own
+    b.free()
+
+
+def pct(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, int(round(q * (len(xs) - 1))))]
+
+
+def parent(args):
+    from quickchem_amd import synth
+    tmp = tempfile.mkdtemp(prefix="ohx_ranks_")
+    model = synth.make_model()
+    path = os.path.join(tmp, "oh.model")
+    open(path, "wb").write(bytes(model.image))
+    result = {"grid": args.grid, "model_file_bytes": os.path.getsize(path), "ticks": args.ticks,
+              "note": "P processes on one GPU, each a rank owning C360/(8P) gridcells in pageable host arrays; "
+                      "aggregate = all ranks' gridcells x ticks / the window from the common start to the last finish",
+              "by_ranks": {}}
+    for P in args.ranks:
+        start_at = time.time() + args.prep_s
+        hold_until = start_at + 600
+        procs = []
+        for r in range(P):
+            cmd = [sys.executable, os.path.abspath(__file__), "--child", "--rank", str(r), "--nranks", str(P), "--model", path,
+                   "--grid", args.grid, "--ticks", str(args.ticks), "--start-at", repr(start_at), "--hold-until", repr(hold_until)]
+            procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        ranks = []
+        for p in procs:                                     # children hold their memory until killed below
+            line = ""
+            for line in p.stdout:
+                if line.startswith("RANK_JSON "):
+                    ranks.append(json.loads(line[len("RANK_JSON "):]))
+                    break
+            else:
+                raise SystemExit(f"a rank died: {line[-500:]}")
+        for p in procs:
+            p.kill()
+            p.wait()
+        entry = {"rows_per_rank": ranks[0]["rows"], "paths_agree_bit_for_bit": all(r["paths_agree_bit_for_bit"] for r in ranks),
+                 "hip_init_s_max": max(r["hip_init_s"] for r in ranks)}
+        held = [r["hbm_free_before"] - r["hbm_free_after"] for r in ranks if r["hbm_free_before"] is not None]
+        if held:
+            entry["hbm_held_all_ranks_bytes"] = max(r["hbm_free_before"] for r in ranks) - min(r["hbm_free_after"] for r in ranks)
+        for mode in ("reference", "fused"):
+            first = [r["ticks_s"][mode][0] for r in ranks]
+            later = [t for r in ranks for t in r["ticks_s"][mode][1:]]
+            w0 = min(r["window"][mode][0] for r in ranks)
+            w1 = max(r["window"][mode][1] for r in ranks)
+            steady0 = max(r["window"][mode][0] + r["ticks_s"][mode][0] for r in ranks)       # every rank past its first tick
+            cells_later = sum(r["rows"] * (len(r["ticks_s"][mode]) - 1) for r in ranks)
+            entry[mode] = {"first_tick_s": {"max": max(first), "min": min(first)},
+                           "tick_ms": {"p50": pct(later, 0.5) * 1e3, "p95": pct(later, 0.95) * 1e3, "max": max(later) * 1e3},
+                           "aggregate_gridcells_per_s_after_first_tick": cells_later / max(w1 - steady0, 1e-9),
+                           "aggregate_gridcells_per_s_whole_window": sum(r["rows"] * len(r["ticks_s"][mode]) for r in ranks) / (w1 - w0)}
+        result["by_ranks"][str(P)] = entry
+        print(f"# P={P}: " + json.dumps(entry), file=sys.stderr, flush=True)
+    print(json.dumps(result))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ranks", default="1,2,3,6")
+    ap.add_argument("--grid", default="C360")
+    ap.add_argument("--ticks", type=int, default=10)
+    ap.add_argument("--prep-s", type=float, default=60.0, help="time the ranks get to build their host arrays before the common start")
+    ap.add_argument("--child", action="store_true")
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--nranks", type=int, default=1)
+    ap.add_argument("--model", default="")
+    ap.add_argument("--start-at", type=float, default=0.0)
+    ap.add_argument("--hold-until", type=float, default=0.0)
+    args = ap.parse_args()
+    if args.child:
+        return child(args)
+    args.ranks = [int(x) for x in args.ranks.split(",")]
+    if max(args.ranks) > 6:
+        raise SystemExit("at most 6 processes may use the GPU at once on this pool (gpurun's process guard)")
+    parent(args)
+
+
+if __name__ == "__main__":
+    main()
