@@ -49,8 +49,11 @@ def child(args):
     # the rank's block, pageable host memory: the reference's xx_carr rows, and the same block as 27 SoA fields
     # (a (360, jm, 72) sub-domain generated as a grid of its own, seeded by the rank)
     seed = synth.FEATURE_SEED + args.rank
-    rows = synth.rows_cpu(sub, 0, n, seed=seed)
     fields = [np.ascontiguousarray(synth.field_cpu(sub, f, seed=seed).T) for f in range(synth.NFEAT)]
+    rows = np.empty((n, synth.NFEAT), dtype=np.float32)            # the gather of :308-345, PL / 100 in float32
+    for f in range(synth.NFEAT):
+        col = np.tile(fields[f].reshape(-1), km) if synth.IS2D[f] else fields[f].reshape(-1)
+        rows[:, f] = col / np.float32(100.0) if f == synth.PL_FEATURE else col
     oh = np.zeros(n, dtype=np.float32)
     free0, total = None, None
     out = {"rank": args.rank, "rows": n, "pid": os.getpid()}
@@ -60,6 +63,7 @@ def child(args):
     free_before, total = hbm_free_bytes()                  # first HIP call of the process: context creation
     out["hip_init_s"] = time.time() - t_begin
     ticks = {"reference": [], "fused": []}
+    ends = {"reference": [], "fused": []}
     b = None
     t_ref0 = time.time()
     for tick in range(args.ticks):
@@ -70,6 +74,7 @@ def child(args):
         p = b.predict(d)
         d.free()
         ticks["reference"].append(time.perf_counter() - t0)
+        ends["reference"].append(time.time())
     t_ref1 = time.time()
     ref_sum = float(np.float64(p).sum())
     for tick in range(args.ticks):
@@ -77,10 +82,11 @@ def child(args):
         b.predict_fields(fields, synth.IS2D, synth.PL_FEATURE, im, jm, km, 1, km, synth.XX_MISS, oh, ohscale=1.0,
                          apply_pow10=False)
         ticks["fused"].append(time.perf_counter() - t0)
+        ends["fused"].append(time.time())
     t_fused1 = time.time()
     free_after, _ = hbm_free_bytes()
     same = bool(np.array_equal(oh.view(np.uint32), p.view(np.uint32)))      # both paths, same margins
-    out.update({"ticks_s": ticks, "window": {"reference": [t_ref0, t_ref1], "fused": [t_ref1, t_fused1]},
+    out.update({"ticks_s": ticks, "tick_ends": ends, "window": {"reference": [t_ref0, t_ref1], "fused": [t_ref1, t_fused1]},
                 "paths_agree_bit_for_bit": same, "margin_sum": ref_sum,
                 "hbm_free_before": free_before, "hbm_free_after": free_after, "hbm_total": total})
     print("RANK_JSON " + json.dumps(out), flush=True)
@@ -101,7 +107,8 @@ def parent(args):
     open(path, "wb").write(bytes(model.image))
     result = {"grid": args.grid, "model_file_bytes": os.path.getsize(path), "ticks": args.ticks,
               "note": "P processes on one GPU, each a rank owning C360/(8P) gridcells in pageable host arrays; "
-                      "aggregate = all ranks' gridcells x ticks / the window from the common start to the last finish",
+                      "aggregate = the gridcells of the ticks that end inside the interval in which every rank is "
+                      "past its first tick and none has finished, over that interval",
               "by_ranks": {}}
     for P in args.ranks:
         start_at = time.time() + args.prep_s
@@ -131,14 +138,15 @@ def parent(args):
         for mode in ("reference", "fused"):
             first = [r["ticks_s"][mode][0] for r in ranks]
             later = [t for r in ranks for t in r["ticks_s"][mode][1:]]
-            w0 = min(r["window"][mode][0] for r in ranks)
-            w1 = max(r["window"][mode][1] for r in ranks)
-            steady0 = max(r["window"][mode][0] + r["ticks_s"][mode][0] for r in ranks)       # every rank past its first tick
-            cells_later = sum(r["rows"] * (len(r["ticks_s"][mode]) - 1) for r in ranks)
+            # the interval in which EVERY rank is ticking steadily: from the last rank's first tick's end to the
+            # first rank's last tick's end; a tick counts if it ends inside
+            c0 = max(r["tick_ends"][mode][0] for r in ranks)
+            c1 = min(r["tick_ends"][mode][-1] for r in ranks)
+            cells = sum(r["rows"] * sum(1 for e in r["tick_ends"][mode][1:] if c0 < e <= c1) for r in ranks)
             entry[mode] = {"first_tick_s": {"max": max(first), "min": min(first)},
                            "tick_ms": {"p50": pct(later, 0.5) * 1e3, "p95": pct(later, 0.95) * 1e3, "max": max(later) * 1e3},
-                           "aggregate_gridcells_per_s_after_first_tick": cells_later / max(w1 - steady0, 1e-9),
-                           "aggregate_gridcells_per_s_whole_window": sum(r["rows"] * len(r["ticks_s"][mode]) for r in ranks) / (w1 - w0)}
+                           "common_window_s": c1 - c0,
+                           "aggregate_gridcells_per_s": cells / (c1 - c0) if c1 > c0 else None}
         result["by_ranks"][str(P)] = entry
         print(f"# P={P}: " + json.dumps(entry), file=sys.stderr, flush=True)
     print(json.dumps(result))
@@ -148,7 +156,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ranks", default="1,2,3,6")
     ap.add_argument("--grid", default="C360")
-    ap.add_argument("--ticks", type=int, default=10)
+    ap.add_argument("--ticks", type=int, default=100)
     ap.add_argument("--prep-s", type=float, default=60.0, help="time the ranks get to build their host arrays before the common start")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--rank", type=int, default=0)
