@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--missing-ppm", type=int, default=0, help="inject -999.0/NaN at this rate per million entries")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="cpu_baseline leg: 0 = skip, < 10 = a one-level sample, else the fixed sample (8 levels, 3 ticks)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_inclusive measurement (host-pointer entry points)")
     ap.add_argument("--shuffle", action="store_true", help="permute the rows (destroys spatial coherence)")
     ap.add_argument("--infer-grid", action="store_true",
                     help="rows path: no hint either, but let the library look for the level size in the rows "
@@ -238,6 +239,53 @@ def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
         if not same:
             raise SystemExit("bench: GPU margins differ from the REAL libxgboost found on this machine")
     return base
+
+
+def pcie_inclusive(grid, booster, dev):
+    """What the reference's own call sequence costs when the batch starts in PAGEABLE HOST memory, as a GEOS rank
+    hands it over (never `value`): one C360/8-sized row shard through XGDMatrixCreateFromMat -> XGBoosterPredict ->
+    XGDMatrixFree (OH_GridCompMod.F90:347,356,377), and the same gridcells as 27 SoA fields through the fused
+    OHXBoosterPredictFields.  Ticks after the first (the first pays hipMalloc of the matrix and the staging buffers)."""
+    from quickchem_amd import capi, synth
+    im, jm_all, km = grid
+    jm = max(1, jm_all // 8)
+    sub = (im, jm, km)
+    n = im * jm * km
+    t = torch.empty((n, synth.NFEAT), dtype=torch.float32, device=dev)
+    synth.rows_device(sub, 0, n, t)
+    rows = t.cpu().numpy()
+    del t
+    ticks = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        d = capi.DMatrix(rows, missing=synth.XX_MISS)
+        t1 = time.perf_counter()
+        booster.predict(d)
+        t2 = time.perf_counter()
+        d.free()
+        ticks.append((time.perf_counter() - t0, t1 - t0, t2 - t1))
+    ref = min(ticks[1:])
+    fields = []
+    for f in range(synth.NFEAT):
+        ft = torch.empty(im * jm * (1 if synth.IS2D[f] else km), dtype=torch.float32, device=dev)
+        synth.field_device(sub, f, ft)
+        fields.append(ft.cpu().numpy())
+        del ft
+    oh = np.zeros(n, dtype=np.float32)
+    fused = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        booster.predict_fields(fields, synth.IS2D, synth.PL_FEATURE, im, jm, km, 1, km, synth.XX_MISS, oh, ohscale=0.85)
+        fused.append(time.perf_counter() - t0)
+    booster.lib.OHXReleaseScratch()
+    return {"rows": n, "bytes_host_to_device": int(rows.nbytes), "host_memory": "pageable",
+            "reference_calls": {"tick_ms": ref[0] * 1e3, "XGDMatrixCreateFromMat_ms": ref[1] * 1e3,
+                                "XGBoosterPredict_ms": ref[2] * 1e3, "gridcells_per_s": n / ref[0],
+                                "first_tick_ms": ticks[0][0] * 1e3},
+            "fused_call": {"tick_ms": min(fused[1:]) * 1e3, "gridcells_per_s": n / min(fused[1:]),
+                           "first_tick_ms": fused[0] * 1e3},
+            "note": "one process, one C360/8-sized block; several ranks sharing the GPU overlap each other's copies: "
+                    "profiles/r03_ranks_per_gpu.json"}
 
 
 def bench_run1(args, grid, n_total, model, booster, dev, t_model):
@@ -603,6 +651,9 @@ def main():
             raise SystemExit("bench: GPU margins differ from the oracle on the first rows of the batch")
         cpu["margins_bit_identical_on_first_rows"] = n_chk
 
+    pcie = None
+    if rank == 0 and world == 1 and plain and not args.no_pcie and args.cpu_seconds > 0 and use_grid:
+        pcie = pcie_inclusive(grid, booster, dev)
     if rank == 0:
         traffic, traffic_src = (None, "not the default single-GPU workload")
         if world == 1 and use_grid and plain and not args.param:
@@ -645,6 +696,7 @@ def main():
                          # texture addresser, priced at the 14 cycles a wave64 gather costs at the very least
                          "gather_issue": gather_issue(info, n_local, kernel_s, dev)},
             "cpu_baseline": cpu,
+            "pcie_inclusive": pcie,
         }
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:

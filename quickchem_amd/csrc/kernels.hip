@@ -583,8 +583,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
       else load_row27(regs, a.rows, valid ? row : 0);
     }
     while (tile_id < a.tile_end) {
-      const bool lane_nan = together ? store_pieces(tile_base, regs, a, __ballot(valid), lane, missing_is_nan)
-                                     : store_row27(tile, regs, valid, a.missing, missing_is_nan, a.flags);
+      // a tile none of whose lanes carries a row (bricks are laid over whole levels: a matrix that ends inside a
+      // level, or is smaller than one, leaves such tiles behind it) is not filled and not walked
+      const bool live = __any(valid);
+      const bool lane_nan = !live ? false
+                            : together ? store_pieces(tile_base, regs, a, __ballot(valid), lane, missing_is_nan)
+                                       : store_row27(tile, regs, valid, a.missing, missing_is_nan, a.flags);
       const uint64_t next = tile_id + nwaves;
       const uint64_t this_row = row;
       const bool this_valid = valid;
@@ -600,8 +604,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
-      if (this_valid) __builtin_nontemporal_store(acc, out + this_row);
+      if (live) {
+        const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
+        if (this_valid) __builtin_nontemporal_store(acc, out + this_row);
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -612,6 +618,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
     bool valid;
     const uint64_t row = launch_row(a, tile_id, lane, &valid);
+    if (!__any(valid)) continue;                      // nothing of the matrix in this tile
     const bool lane_nan = fill_tile_rows(tile, a.rows, row, valid, a.ncol, fr.num_feature, a.missing,
                                          missing_is_nan, a.flags);
     const bool wave_nan = __any(lane_nan);
