@@ -100,6 +100,9 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *   "ohx_cluster"     auto | on | off : group rows of no known order by the decisions they take at the top of
  *                     the first trees before walking them ("ohx_cluster_trees", "ohx_cluster_steps",
  *                     "ohx_cluster_zorder" shape the key)
+ *   "ohx_defer_missing"  auto | on | off : rows that hold missing values are predicted by a second, small launch
+ *                     instead of putting their whole wavefront on the missing-aware walk (auto = batches of 262 144
+ *                     rows and more)
  *   "ohx_launches_per_residency"  tiles per wave per launch (default 2; 0 = one launch)
  *   "ohx_brick" = "a,b,c", "ohx_brick_k_fastest", "ohx_prefetch", "ohx_coop_rows", "ohx_xcd_remap", "ohx_lds_pad", "ohx_overlap_group"
  *                     launch-shape knobs behind profiles/ *_sweeps.txt; the defaults are the measured best

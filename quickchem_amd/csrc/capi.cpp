@@ -271,6 +271,7 @@ struct BoosterObj {
     if (train.fork) (void)hipEventDestroy(train.fork);
     if (train.join) (void)hipEventDestroy(train.join);
     if (cluster_done) (void)hipEventDestroy(cluster_done);
+    if (defer_seen) (void)hipEventDestroy(defer_seen);
   }
   TrainStreams train;              // second stream of the launch train (kernels.hpp), made at upload
   Forest forest;
@@ -298,6 +299,13 @@ struct BoosterObj {
   std::string symbol;                   // OHXBoosterKernelSymbol's answer
   DevBuf<uint32_t> d_roots;
   DevBuf<uint32_t> d_flags;
+  DevBuf<uint32_t> d_defer;             // deferred rows (kernels.hpp PredictArgs::defer_list): the count, then the list
+  // how many rows of the last batch held missing values (read back behind the batch, looked at before the next one)
+  PinnedBuf<uint32_t> h_defer_count;
+  hipEvent_t defer_seen = nullptr;
+  bool defer_pending = false;
+  uint64_t defer_last_nrow = 0;
+  bool defer_too_many = false;
   DevBuf<float> d_pred;
   PinnedBuf<float> h_pred;
   hipStream_t s_copy = nullptr, s_exec = nullptr;   // fused host path: PCIe copies beside the kernels
@@ -693,7 +701,30 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
   tune.grid_jm = d.grid_jm;
   tune.grid_row0 = d.grid_row0;
   a.perm = cluster_rows(b, d, a, pred_leaf, kind, stream);
+  // rows with missing values leave for a second, small launch instead of slowing their whole wave down (big batches)
+  if (a.perm == nullptr && !pred_leaf && d.ncol == 27 && tune.defer_missing != 0 &&
+      (tune.defer_missing > 0 || d.nrow >= (1u << 18))) {
+    // The second launch pays while few rows hold missing values (1e-4 of the entries: +2 % instead of +17 %); from
+    // about one row in fifty on it costs what it saves, and more beyond (profiles/r03_sweeps.txt).  The count
+    // of the last batch - read back behind it, never waited for - decides; the reference's ticks resemble each other.
+    if (b.defer_pending && hipEventQuery(b.defer_seen) == hipSuccess) {
+      b.defer_pending = false;
+      b.defer_too_many = (uint64_t)b.h_defer_count.p[0] * 50u > b.defer_last_nrow;        // more than 2 % of the rows
+    }
+    b.d_defer.ensure((size_t)(d.nrow / 32 + 1024 + 1));
+    tune.defer_buf = b.d_defer.p;
+    tune.defer_words = b.d_defer.n;
+    tune.defer_count_only = (b.defer_too_many && tune.defer_missing < 0) ? 1 : 0;
+  }
   HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, tune));
+  if (tune.defer_buf != nullptr && !b.defer_pending) {
+    if (b.defer_seen == nullptr) HIP_CHECK(hipEventCreateWithFlags(&b.defer_seen, hipEventDisableTiming));
+    b.h_defer_count.ensure(1);
+    HIP_CHECK(hipMemcpyAsync(b.h_defer_count.p, b.d_defer.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipEventRecord(b.defer_seen, stream));
+    b.defer_pending = true;
+    b.defer_last_nrow = d.nrow;
+  }
   if (a.perm != nullptr) {
     if (b.cluster_done == nullptr) HIP_CHECK(hipEventCreateWithFlags(&b.cluster_done, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(b.cluster_done, stream));
@@ -1008,6 +1039,9 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     b->tune.cluster_steps = std::max(1, atoi(value));
   } else if (n == "ohx_lds_pad") {
     b->tune.lds_pad = atoi(value);
+  } else if (n == "ohx_defer_missing") {
+    if (v != "auto" && v != "on" && v != "off") throw OhxError("ohx_defer_missing must be auto, on or off");
+    b->tune.defer_missing = v == "auto" ? -1 : (v == "on" ? 1 : 0);
   } else if (n == "ohx_prefetch") {
     b->tune.prefetch = atoi(value) != 0;
   } else if (n == "ohx_coop_rows") {

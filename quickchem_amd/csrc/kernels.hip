@@ -86,11 +86,14 @@ __device__ __forceinline__ uint64_t tile_row(const TileShape& sh, uint64_t tile_
 }
 
 // the same for a launch: rows grouped by the clustering pass come through the permutation
-__device__ __forceinline__ uint64_t launch_row(const PredictArgs& a, uint64_t tile_id, int lane, bool* valid) {
+__device__ __forceinline__ uint64_t launch_row(const PredictArgs& a, uint64_t tile_id, int lane, bool* valid,
+                                               uint64_t perm_slots = ~0ull) {
   if (a.perm != nullptr) {
     const uint64_t slot = tile_id * kWave + lane;
-    *valid = slot < a.nrow;
-    return *valid ? (uint64_t)a.perm[slot] : 0;
+    *valid = a.perm_count != nullptr ? slot < perm_slots : slot < a.nrow;
+    const uint32_t row = *valid ? a.perm[slot] : 0u;
+    if (row == 0xFFFFFFFFu && a.perm_count != nullptr) *valid = false;      // a slot of the deferred list nobody wrote
+    return *valid ? (uint64_t)row : 0;
   }
   return tile_row(a.shape, tile_id, lane, a.nrow, valid);
 }
@@ -598,15 +601,46 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
         if (together) load_pieces(regs, a, row, lane);   // in flight during the walk
         else load_row27(regs, a.rows, valid ? row : 0);
       }
-      const bool wave_nan = __any(lane_nan);
+      bool wave_nan = __any(lane_nan);
+      bool keep = this_valid;
       // fetched together, the tile was written by all lanes for all lanes: LDS serves a wave's instructions in
       // order; the fences and the wave barriers keep the compiler from moving reads and writes across
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // rows with missing values leave for the second launch: this wave then walks without missing-value logic
+      // (a NaN compares false everywhere: those lanes walk some path of every tree to its end and are not stored)
+      if (wave_nan && a.defer_count != nullptr && a.defer_cap == 0u) {
+        // only counting (the host saw too many such rows in the last batch for the second launch to pay): an
+        // estimate from every eighth tile, so that nearly every wave of a batch full of missing values does not
+        // queue at one counter; nobody waits for the sum
+        if ((tile_id & 7u) == 0u) {
+          const uint32_t n = 8u * (uint32_t)__popcll(__ballot(lane_nan));
+          if (lane == 0) atomicAdd(a.defer_count, n);
+        }
+      } else if (wave_nan && a.defer_count != nullptr) {
+        // whose row it is that holds the NaN: a lane that filled pieces of the tile saw other lanes' elements
+        bool mine = false;
+#pragma unroll
+        for (int f = 0; f < 27; ++f) {
+          const float x = tile[f * kWave];
+          mine |= (x != x);
+        }
+        const bool leaves = mine && this_valid;
+        const uint64_t who = __ballot(leaves);
+        const uint32_t n = (uint32_t)__popcll(who);
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(a.defer_count, n);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (at + n <= a.defer_cap) {               // room for all of them (a full list stays full: later waves walk as before)
+          if (leaves) a.defer_list[at + (uint32_t)__popcll(who & ((1ull << lane) - 1ull))] = (uint32_t)this_row;
+          keep = this_valid && !mine;
+          wave_nan = false;
+        }
+      }
       if (live) {
         const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
-        if (this_valid) __builtin_nontemporal_store(acc, out + this_row);
+        if (keep) __builtin_nontemporal_store(acc, out + this_row);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -615,9 +649,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
     }
     return;
   }
-  for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
+  // the second launch of a deferred-rows predict: how many slots the first one filled is only known on the device
+  uint64_t slots = ~0ull, tile_end = a.tile_end;
+  if (a.perm_count != nullptr) {
+    const uint32_t filled = *a.perm_count;
+    slots = filled < a.perm_slots ? filled : a.perm_slots;
+    const uint64_t need = (slots + kWave - 1) / kWave;
+    tile_end = need < tile_end ? need : tile_end;
+  }
+  for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < tile_end; tile_id += nwaves) {
     bool valid;
-    const uint64_t row = launch_row(a, tile_id, lane, &valid);
+    const uint64_t row = launch_row(a, tile_id, lane, &valid, slots);
     if (!__any(valid)) continue;                      // nothing of the matrix in this tile
     const bool lane_nan = fill_tile_rows(tile, a.rows, row, valid, a.ncol, fr.num_feature, a.missing,
                                          missing_is_nan, a.flags);
@@ -1175,6 +1217,26 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
   return hipGetLastError();
 }
 
+// The second launch of a deferred-rows predict: the rows of the list, 64 per wave, each lane its own row, missing-aware.
+template <class K>
+hipError_t launch_deferred(K kernel, size_t lds, const DeviceForest& fr, PredictArgs a, int num_cus, hipStream_t stream) {
+  hipError_t e = ensure_lds(kernel, lds);
+  if (e != hipSuccess) return e;
+  a.perm = a.defer_list;
+  a.perm_count = a.defer_count;
+  a.perm_slots = a.defer_cap;
+  a.defer_list = nullptr;
+  a.defer_count = nullptr;
+  a.shape = TileShape();
+  a.run_log = 0;
+  a.run_lo_bits = 0;
+  a.tile_begin = 0;
+  a.tile_end = ((uint64_t)a.defer_cap + kWave - 1) / kWave;
+  const int grid = tile_grid(kernel, lds, a.tile_end, num_cus);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, fr, a, fr.super_heads, a.out);
+  return hipGetLastError();
+}
+
 
 }  // namespace
 
@@ -1192,9 +1254,10 @@ const char* kernel_kind_name(KernelKind k) {
   return "?";
 }
 
-hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const PredictArgs& a, int num_cus,
+hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const PredictArgs& a_in, int num_cus,
                           hipStream_t stream, const LaunchTuning& tune) {
-  if (a.nrow == 0) return hipSuccess;
+  if (a_in.nrow == 0) return hipSuccess;
+  PredictArgs a = a_in;
   const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
                         kind == KernelKind::Super4;
   const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
@@ -1209,9 +1272,28 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
   }
   // every wave gets more than one tile per launch and the rows are the OH shape: prefetch
   const bool pf = a.ncol == 27 && fr.num_feature == 27 && tune.launches_per_residency != 1 && tune.prefetch;
+  // rows with missing values are left to a second launch (PredictArgs::defer_list)
+  constexpr uint64_t kDeferMinRows = 1u << 18;
+  const bool defer = pf && a.perm == nullptr && tune.defer_buf != nullptr && tune.defer_words >= 2 && a.nrow < 0xFFFFFFF0ull &&
+                     (tune.defer_missing > 0 || (tune.defer_missing < 0 && a.nrow >= kDeferMinRows));
+  const bool listing = defer && !tune.defer_count_only;
+  if (defer) {
+    const uint64_t want = a.nrow / 32 + 1024;                                   // room for ~3 % of the rows
+    a.defer_cap = listing ? (uint32_t)(want < tune.defer_words - 1 ? want : tune.defer_words - 1) : 0u;
+    a.defer_count = tune.defer_buf;
+    a.defer_list = tune.defer_buf + 1;
+    hipError_t e = hipMemsetAsync(a.defer_count, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess && listing) e = hipMemsetAsync(a.defer_list, 0xFF, (size_t)a.defer_cap * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+  }
 #define OHX_ROWS_T(FMT, CH, TOPS)                                                                                  \
-  return pf ? launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, true, TOPS>, lds, fr, a, num_cus, stream, tune)   \
-            : launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, false, TOPS>, lds, fr, a, num_cus, stream, tune)
+  {                                                                                                                \
+    hipError_t e_ = pf ? launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, true, TOPS>, lds, fr, a, num_cus, stream, tune)   \
+                       : launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, false, TOPS>, lds, fr, a, num_cus, stream, tune); \
+    if (e_ == hipSuccess && listing)                                                                               \
+      e_ = launch_deferred(predict_rows_tile_kernel<FMT, CH, false, TOPS>, lds, fr, a, num_cus, stream);           \
+    return e_;                                                                                                     \
+  }
 #define OHX_ROWS(FMT, CH)                    \
   if (fr.tree_tops) OHX_ROWS_T(FMT, CH, true); \
   OHX_ROWS_T(FMT, CH, false)

@@ -50,8 +50,30 @@ struct TileShape {
   uint32_t nbi = 0, nbj = 0, nbk = 0;   // bricks along i, j, k
   uint32_t k_fastest = 0;               // lane order inside a brick: 0 = i, j, k; 1 = k, i, j
   uint64_t ntiles(uint64_t nrow_) const { return im ? (uint64_t)nbi * nbj * nbk : (nrow_ + 63) / 64; }
-  // fraction of lanes that carry a row
-  double fill() const { return im ? (double)nrow / (64.0 * (double)ntiles(nrow)) : 1.0; }
+  // Bricks that hold at least one row.  Bricks are laid over whole levels; the row range may begin and end inside a
+  // level, and the bricks of a slab of levels none of which is complete only count along the j they touch (the
+  // kernels skip a brick without a row).
+  uint64_t live_tiles() const {
+    if (!im) return (nrow + 63) / 64;
+    const uint64_t plane = (uint64_t)im * jm, last = row0 + nrow - 1;
+    uint64_t live = 0;
+    for (uint32_t b = 0; b < nbk; ++b) {
+      uint32_t jlo = jm, jhi = 0;                                  // j range the slab's levels touch, inclusive
+      for (uint32_t d = 0; d < (1u << lk); ++d) {
+        const uint64_t k = (uint64_t)k_first + ((uint64_t)b << lk) + d;
+        const uint64_t lev0 = k * plane, lev1 = lev0 + plane - 1;
+        if (lev1 < row0 || lev0 > last) continue;
+        const uint64_t a = row0 > lev0 ? row0 - lev0 : 0, z = (last < lev1 ? last : lev1) - lev0;
+        const uint32_t j0 = (uint32_t)(a / im), j1 = (uint32_t)(z / im);
+        jlo = j0 < jlo ? j0 : jlo;
+        jhi = j1 > jhi ? j1 : jhi;
+      }
+      if (jhi >= jlo && jlo < jm) live += (uint64_t)nbi * ((jhi >> lj) - (jlo >> lj) + 1);
+    }
+    return live ? live : 1;
+  }
+  // fraction of the lanes of the bricks that are walked that carry a row
+  double fill() const { return im ? (double)nrow / (64.0 * (double)live_tiles()) : 1.0; }
   void set_grid(uint32_t im_, uint32_t jm_, uint64_t row0_, uint64_t nrow_, uint32_t li_, uint32_t lj_, uint32_t lk_) {
     im = im_; jm = jm_; row0 = row0_; nrow = nrow_; li = li_; lj = lj_; lk = lk_;
     const uint64_t plane = (uint64_t)im * jm;
@@ -95,6 +117,17 @@ struct PredictArgs {
   uint64_t tile_end = 0;        // one past the last tile of this launch
   int xcd_remap = 1;            // give each XCD a contiguous range of tiles
   const uint32_t* perm = nullptr;  // rows grouped by the clustering pass: lane l of tile t takes row perm[64 t + l]
+  // ... or the rows a first pass left for a second one (below): then the number of slots is read from *perm_count on
+  // the device (capped by nrow_slots) and a slot holding 0xFFFFFFFF is empty
+  const uint32_t* perm_count = nullptr;
+  uint32_t perm_slots = 0;
+  // Deferred rows (27-column rows with prefetch, big batches).  A wave some of whose rows hold missing values
+  // appends those rows to defer_list (room reserved with one atomicAdd on *defer_count; if the list is full the wave
+  // walks missing-aware as before) and walks the tile WITHOUT missing-value logic; the listed rows are predicted by a
+  // second, small launch through the list.  Zero *defer_count and fill the list with 0xFF before the first launch.
+  uint32_t* defer_list = nullptr;
+  uint32_t* defer_count = nullptr;
+  uint32_t defer_cap = 0;
   // 27-column rows of a tile fetched by the wave together, run of consecutive rows by run (kernels.hip RowPieces):
   // log2 of the rows per run (0 = every lane fetches its own row), and where a run's rows sit among the lanes
   uint32_t run_log = 0, run_lo_bits = 0;
@@ -124,6 +157,15 @@ struct LaunchTuning {
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
   int coop_rows = 1;  // ... fetched by the wave together where a tile is made of runs of >= 4 consecutive rows
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
+  // rows with missing values go to a list and a second small launch (PredictArgs::defer_list) instead of slowing
+  // their whole wave down for every tree: -1 = for batches of 262 144 rows and more, 0 = never, 1 = always;
+  // needs the booster's list buffer (defer_words words: the count, then the list)
+  int defer_missing = -1;
+  // the rows with missing values are only counted (*defer_buf), none is listed: the host saw too many of them in the
+  // last batch for the second launch to pay (capi.cpp)
+  int defer_count_only = 0;
+  uint32_t* defer_buf = nullptr;
+  size_t defer_words = 0;
   // rows in no known order: -1 = decide per matrix (cluster unless the rows look ordered), 0 = never, 1 = always
   int cluster = -1;
   int cluster_trees = 2, cluster_steps = 7, cluster_zorder = 0;

@@ -93,6 +93,35 @@ def test_missing_values_vs_oracle(torch_cuda, deep_model, kernel, missing):
     assert np.array_equal(helpers.bits(got), helpers.bits(want))
 
 
+@pytest.mark.parametrize("kernel", ["packed2", "super2", "super4"])
+@pytest.mark.parametrize("rate", [1e-4, 3e-3, 0.05])
+def test_rows_with_missing_values_left_to_the_second_launch(torch_cuda, deep_model, kernel, rate):
+    """ohx_defer_missing: a wave some of whose rows hold missing values lists those rows for a second, small launch
+    and walks the tile without missing-value logic.  Forced on for a batch below the size at which it is the
+    default; at 5 % of the entries (three rows in four) the list overflows and the later waves walk missing-aware
+    as before.  With the grid hint (bricks, rows fetched together), with 64 consecutive rows per wave, and with a
+    first row inside a level."""
+    grid = (96, 72, 72)
+    rows = with_missing(synth.rows_cpu(grid, 1234, 96 * 72 * 6 + 777), rate, seed=11)
+    want = helpers.oracle_predict(deep_model.image, rows, synth.XX_MISS)
+    assert np.isfinite(want).all()
+    for hint in ((96, 72, 1234), (0, 0, 0)):
+        got = gpu_predict(deep_model.image, rows, synth.XX_MISS, kernel, params={"ohx_defer_missing": "on"}, grid=hint)
+        assert np.array_equal(helpers.bits(got), helpers.bits(want)), hint
+    off = gpu_predict(deep_model.image, rows, synth.XX_MISS, kernel, params={"ohx_defer_missing": "off"}, grid=(96, 72, 1234))
+    assert np.array_equal(helpers.bits(off), helpers.bits(want))
+
+
+def test_deferred_rows_by_default_on_a_big_batch(torch_cuda, small_model):
+    """From 262 144 rows on the second launch is the default; NaN as the missing marker."""
+    grid = (96, 72, 72)
+    rows = with_missing(synth.rows_cpu(grid, 0, 96 * 72 * 40), 2e-4, seed=5)
+    rows[rows == np.float32(synth.XX_MISS)] = np.nan
+    want = helpers.oracle_predict(small_model.image, rows, float("nan"))
+    got = gpu_predict(small_model.image, rows, float("nan"), "super2", grid=(96, 72, 0))
+    assert np.array_equal(helpers.bits(got), helpers.bits(want))
+
+
 @pytest.mark.parametrize("kernel", ["wide", "packed4", "super2"])
 def test_ntree_limit_and_leaf_indices(torch_cuda, small_model, kernel):
     rows = with_missing(synth.rows_cpu(synth.GRIDS["C12"], 0, 3000), 0.005)
