@@ -381,16 +381,22 @@ def measured_traffic(grid_name, kernel, model_nodes):
     return None, why
 
 
-def gather_issue(info, nrows, kernel_s, dev):
+def gather_issue(info, nrows, kernel_s, dev, row_loads_per_tile):
+    """The roofline that really bounds the walk: wave64 vector-memory instructions through the texture
+    addresser, priced at the 14 cycles one costs at the very least.  Instructions per tile = what the library says a
+    wave issues to walk the forest once (OHXBoosterGetInfo[7]: per tree one coalesced tree-top load and one gather
+    per step after the third) + the loads of the tile's rows (7 sixteen-byte pieces per lane when the wave fetches
+    them together, 9 when every lane loads its own 27 floats).  The clock is the device's own maximum."""
     import torch
     props = torch.cuda.get_device_properties(dev)
     tiles = -(-nrows // 64)
-    gathers = tiles * (info.get("gathers_per_wave", 0) + 7)          # + the 7 loads of a tile's 27-float rows
-    clock_hz = 2.4e9                                                 # MI355X max clock (MI355X_MICROARCH.md)
+    gathers = tiles * (info.get("gathers_per_wave", 0) + row_loads_per_tile)
+    clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3      # kHz -> Hz; MI355X: 2.4 GHz
     peak = props.multi_processor_count * clock_hz / 14.0
     return {"unit": "wave64 gathers/s", "achieved": gathers / kernel_s, "peak": peak,
             "frac": gathers / kernel_s / peak,
             "gathers_per_wave_and_tree": info.get("gathers_per_wave", 0) / max(info["num_trees"], 1),
+            "row_loads_per_tile": row_loads_per_tile,
             "min_cycles_per_gather": 14, "cus": props.multi_processor_count, "clock_mhz": clock_hz / 1e6}
 
 
@@ -672,6 +678,8 @@ def main():
                           "mean_path": round(model.mean_path, 3), "seed": synth.MODEL_SEED,
                           "build_s": round(t_model, 2)},
                 "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid), "grid_known_to_library": list(dmats[0].grid()), "verified": verified,
+                "verified_against": ("the whole timed output, bit for bit, against the `wide` kernel (other node format, no LDS tile, no grid hint); "
+                                     "the CPU oracle sees the first 2^18 rows (cpu_baseline.margins_bit_identical_on_first_rows)") if verified else None,
                 "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
                 "gather_via": (args.gather if (world > 1 or force_dist) else None),
             },
@@ -694,7 +702,7 @@ def main():
                          "algorithmic_bytes": algo_bytes,
                          # what actually bounds the walk: gather instructions through the
                          # texture addresser, priced at the 14 cycles a wave64 gather costs at the very least
-                         "gather_issue": gather_issue(info, n_local, kernel_s, dev)},
+                         "gather_issue": gather_issue(info, n_local, kernel_s, dev, 7 if (use_grid or args.consecutive or args.infer_grid or args.no_grid) and not args.shuffle else 9)},
             "cpu_baseline": cpu,
             "pcie_inclusive": pcie,
         }
