@@ -518,7 +518,7 @@ __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTr
     return wave_has_missing ? walk_packed<CHAINS, true>(nodes, fr.roots, t0, t1, acc, tile)
                             : walk_packed<CHAINS, false>(nodes, fr.roots, t0, t1, acc, tile);
   } else if constexpr (FMT == 2) {
-    // plain 128-bit global loads: measured 8 % faster than buffer loads on the divergent deep levels
+    // the deep gathers go through a buffer descriptor over the forest (walk_super); the tree tops are plain loads
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.super);
     return wave_has_missing ? walk_super<CHAINS, true, TOPS>(nodes, heads, t0, t1, acc, tile, first, nfirst, fr.super_bytes)
                             : walk_super<CHAINS, false, TOPS>(nodes, heads, t0, t1, acc, tile, first, nfirst, fr.super_bytes);
