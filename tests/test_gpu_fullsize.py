@@ -180,6 +180,30 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(tmp_path):
             assert line["config"]["gather_pieces"] == 0 and line["config"]["gather_via"] == "none"
 
 
+def test_bench_over_rccl_with_one_rank():
+    """What the driver's N > 1 runs execute, as far as one GPU can: bench.py with the RCCL process group of ONE rank
+    (OHX_BENCH_FORCE_DIST=1) - the chunked all-gather through torch.distributed, the C ABI's OHXAllGatherOH, and the
+    predict-only control; the line carries the phases and the record of who ran where over which RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OHX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
+    for gather in ("torch", "native", "none"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--grid", "C90", "--steps", "2",
+                            "--warmup", "1", "--cpu-seconds", "0", "--gather", gather],
+                           capture_output=True, text=True, env=env, timeout=900, cwd=root)
+        assert r.returncode == 0, (gather, r.stdout[-1500:], r.stderr[-3000:])
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["config"]["verified"] is True and line["config"]["gather_via"] == gather
+        d = line["distributed"]
+        assert d["backend"] == "nccl" and d["world_size"] == 1 and len(d["ranks"]) == 1
+        assert d["rccl_version"] and d["rccl_version"] >= 20000
+        ph = line["phases"]
+        assert ph["predict_ms"] > 0 and ph["gather_bytes_total"] == 4 * 90 * 540 * 72
+        assert line["config"]["gather_pieces"] == (0 if gather == "none" else len(ph["pieces"]))
+
+
 def test_native_all_gather_entry_points_on_one_rank():
     """include/ohxgb.h part 4 with the one GPU of the box: RCCL is found and loaded by libohxgb.so itself, a
     communicator of one rank is built from a unique id, and OHXAllGatherOH puts the shard at its rows - out of place
