@@ -672,6 +672,33 @@ const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a,
   return sorted;
 }
 
+// Deferred rows (kernels.hpp PredictArgs::defer_list).  The second launch pays while few rows hold missing values
+// (1e-4 of the entries: +2 % instead of +17 %); from about one row in fifty on it costs what it saves, and more beyond
+// (profiles/r03_sweeps.txt).  The count of the last batch - read back behind it, never waited for - decides; the
+// reference's ticks resemble each other.  Returns whether the launch will count (and maybe list) such rows.
+bool defer_prepare(BoosterObj& b, uint64_t nrow, LaunchTuning& tune) {
+  if (tune.defer_missing == 0 || !(tune.defer_missing > 0 || nrow >= (1u << 18))) return false;
+  if (b.defer_pending && hipEventQuery(b.defer_seen) == hipSuccess) {
+    b.defer_pending = false;
+    b.defer_too_many = (uint64_t)b.h_defer_count.p[0] * 50u > b.defer_last_nrow;        // more than 2 % of the rows
+  }
+  b.d_defer.ensure((size_t)(nrow / 32 + 1024 + 1));
+  tune.defer_buf = b.d_defer.p;
+  tune.defer_words = b.d_defer.n;
+  tune.defer_count_only = (b.defer_too_many && tune.defer_missing < 0) ? 1 : 0;
+  return true;
+}
+
+void defer_look(BoosterObj& b, uint64_t nrow, hipStream_t stream) {
+  if (b.defer_pending) return;
+  if (b.defer_seen == nullptr) HIP_CHECK(hipEventCreateWithFlags(&b.defer_seen, hipEventDisableTiming));
+  b.h_defer_count.ensure(1);
+  HIP_CHECK(hipMemcpyAsync(b.h_defer_count.p, b.d_defer.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipEventRecord(b.defer_seen, stream));
+  b.defer_pending = true;
+  b.defer_last_nrow = nrow;
+}
+
 void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsigned ntree_limit, float* d_out,
                             hipStream_t stream) {
   bool pred_leaf = false;
@@ -702,29 +729,9 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
   tune.grid_row0 = d.grid_row0;
   a.perm = cluster_rows(b, d, a, pred_leaf, kind, stream);
   // rows with missing values leave for a second, small launch instead of slowing their whole wave down (big batches)
-  if (a.perm == nullptr && !pred_leaf && d.ncol == 27 && tune.defer_missing != 0 &&
-      (tune.defer_missing > 0 || d.nrow >= (1u << 18))) {
-    // The second launch pays while few rows hold missing values (1e-4 of the entries: +2 % instead of +17 %); from
-    // about one row in fifty on it costs what it saves, and more beyond (profiles/r03_sweeps.txt).  The count
-    // of the last batch - read back behind it, never waited for - decides; the reference's ticks resemble each other.
-    if (b.defer_pending && hipEventQuery(b.defer_seen) == hipSuccess) {
-      b.defer_pending = false;
-      b.defer_too_many = (uint64_t)b.h_defer_count.p[0] * 50u > b.defer_last_nrow;        // more than 2 % of the rows
-    }
-    b.d_defer.ensure((size_t)(d.nrow / 32 + 1024 + 1));
-    tune.defer_buf = b.d_defer.p;
-    tune.defer_words = b.d_defer.n;
-    tune.defer_count_only = (b.defer_too_many && tune.defer_missing < 0) ? 1 : 0;
-  }
+  const bool deferring = a.perm == nullptr && !pred_leaf && d.ncol == 27 && defer_prepare(b, d.nrow, tune);
   HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, tune));
-  if (tune.defer_buf != nullptr && !b.defer_pending) {
-    if (b.defer_seen == nullptr) HIP_CHECK(hipEventCreateWithFlags(&b.defer_seen, hipEventDisableTiming));
-    b.h_defer_count.ensure(1);
-    HIP_CHECK(hipMemcpyAsync(b.h_defer_count.p, b.d_defer.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipEventRecord(b.defer_seen, stream));
-    b.defer_pending = true;
-    b.defer_last_nrow = d.nrow;
-  }
+  if (deferring) defer_look(b, d.nrow, stream);
   if (a.perm != nullptr) {
     if (b.cluster_done == nullptr) HIP_CHECK(hipEventCreateWithFlags(&b.cluster_done, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(b.cluster_done, stream));
@@ -1150,9 +1157,14 @@ int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fie
   a.out = d_oh_ml;
   a.margin_out = d_margin;
   if (pick_kernel(*b) == KernelKind::Wide) ensure_wide(*b);
-  if (a.k2 >= a.k1)
+  if (a.k2 >= a.k1) {
+    const uint64_t nrow = (uint64_t)im * (uint64_t)jm * (uint64_t)(a.k2 - a.k1 + 1);
+    LaunchTuning tune = b->tune;
+    const bool deferring = nfield == 27 && defer_prepare(*b, nrow, tune);
     HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus,
-                                    static_cast<hipStream_t>(stream), b->tune));
+                                    static_cast<hipStream_t>(stream), tune));
+    if (deferring) defer_look(*b, nrow, static_cast<hipStream_t>(stream));
+  }
   API_END();
 }
 
@@ -1219,7 +1231,11 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
     piece.k2 = a.k1 + (int)l1 - 1;
     // rows of this piece start at plane * l0 of the slab-ordered margin buffer
     piece.margin_out = margin_base ? const_cast<float*>(margin_base) + plane * l0 : nullptr;
-    HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), piece, b->dev.num_cus, b->s_exec, b->tune));
+    LaunchTuning tune = b->tune;
+    const uint64_t piece_rows = plane * (l1 - l0);
+    const bool deferring = nfield == 27 && defer_prepare(*b, piece_rows, tune);
+    HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), piece, b->dev.num_cus, b->s_exec, tune));
+    if (deferring) defer_look(*b, piece_rows, b->s_exec);
   }
   HIP_CHECK(hipMemcpyAsync(oh_ml + plane * (size_t)a.k1, b->d_stage_out.p, nrow * sizeof(float), hipMemcpyDeviceToHost,
                            b->s_exec));
@@ -1303,7 +1319,11 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
     fa.out = oh_ml;
     fa.flags = b.d_flags.p;
     if (pick_kernel(b) == KernelKind::Wide) ensure_wide(b);
-    HIP_CHECK(launch_predict_fields(pick_kernel(b), device_forest(b), fa, b.dev.num_cus, stream, b.tune));
+    const uint64_t slab_rows = plane * (uint64_t)(k2 - k1 + 1);
+    LaunchTuning tune = b.tune;
+    const bool deferring = defer_prepare(b, slab_rows, tune);
+    HIP_CHECK(launch_predict_fields(pick_kernel(b), device_forest(b), fa, b.dev.num_cus, stream, tune));
+    if (deferring) defer_look(b, slab_rows, stream);
   }
   PostArgs po;
   po.im = r.im; po.jm = r.jm; po.km = r.km;

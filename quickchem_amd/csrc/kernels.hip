@@ -729,9 +729,27 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
   const uint64_t wave_id = (uint64_t)block * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
   const float qnan = __builtin_nanf("");
-  for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < a.tile_end; tile_id += nwaves) {
+  // the second launch of a deferred-rows call (PredictArgs::defer_list): the rows of the list, as many as the first filled
+  uint64_t slots = 0, tile_end = a.tile_end;
+  if (a.perm != nullptr) {
+    const uint32_t filled = *a.perm_count;
+    slots = filled < a.perm_slots ? filled : a.perm_slots;
+    const uint64_t need = (slots + kWave - 1) / kWave;
+    tile_end = need < tile_end ? need : tile_end;
+  }
+  for (uint64_t tile_id = a.tile_begin + wave_id; tile_id < tile_end; tile_id += nwaves) {
     bool valid;
-    const uint64_t m = tile_row(a.shape, tile_id, lane, nrow, &valid);
+    uint64_t m;
+    if (a.perm != nullptr) {
+      const uint64_t slot = tile_id * kWave + lane;
+      valid = slot < slots;
+      const uint32_t listed = valid ? a.perm[slot] : 0u;
+      valid = valid && listed != 0xFFFFFFFFu;
+      m = valid ? listed : 0u;
+    } else {
+      m = tile_row(a.shape, tile_id, lane, nrow, &valid);
+    }
+    if (!__any(valid)) continue;                       // a brick without a row of the slab, a tile of empty slots
     const uint64_t col = valid ? m % plane : 0;
     bool lane_nan = false, any_inf = false;
     // The fields come one after the other, each load waited for before the next is issued.  Issuing the OH gather's
@@ -752,9 +770,29 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
       tile[f * kWave] = x;
     }
     if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
-    const bool wave_nan = __any(lane_nan);
+    bool wave_nan = __any(lane_nan);
+    bool keep = valid;
+    // rows with missing values leave for the second launch, as in the rows kernel (every lane filled its own row here)
+    if (wave_nan && a.defer_count != nullptr && a.defer_cap == 0u) {
+      if ((tile_id & 7u) == 0u) {
+        const uint32_t n = 8u * (uint32_t)__popcll(__ballot(lane_nan && valid));
+        if (lane == 0) atomicAdd(a.defer_count, n);
+      }
+    } else if (wave_nan && a.defer_count != nullptr) {
+      const bool leaves = lane_nan && valid;
+      const uint64_t who = __ballot(leaves);
+      const uint32_t n = (uint32_t)__popcll(who);
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(a.defer_count, n);
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+      if (at + n <= a.defer_cap) {
+        if (leaves) a.defer_list[at + (uint32_t)__popcll(who & ((1ull << lane) - 1ull))] = (uint32_t)m;
+        keep = valid && !lane_nan;
+        wave_nan = false;
+      }
+    }
     const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
-    if (valid) {
+    if (keep) {
       if (margin_out) margin_out[m] = acc;
       float oh = acc;
       // 10.0**x rounded once from double: agrees with a correctly rounded powf
@@ -1341,6 +1379,18 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
   if (a.shape.ntiles(nrow) >= 0xFFFFFFFFull) a.shape = TileShape();
   const uint64_t ntiles = a.shape.ntiles(nrow);
   const int grid = tile_grid(kernel, lds, ntiles, num_cus);
+  // rows with missing values are left to a second launch (PredictArgs::defer_list)
+  constexpr uint64_t kDeferMinRows = 1u << 18;
+  if (tune.defer_buf != nullptr && tune.defer_words >= 2 && nrow < 0xFFFFFFF0ull && fr.num_feature == 27 &&
+      (tune.defer_missing > 0 || (tune.defer_missing < 0 && nrow >= kDeferMinRows))) {
+    const uint64_t want = nrow / 32 + 1024;
+    a.defer_cap = tune.defer_count_only ? 0u : (uint32_t)(want < tune.defer_words - 1 ? want : tune.defer_words - 1);
+    a.defer_count = tune.defer_buf;
+    a.defer_list = tune.defer_buf + 1;
+    e = hipMemsetAsync(a.defer_count, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess && a.defer_cap) e = hipMemsetAsync(a.defer_list, 0xFF, (size_t)a.defer_cap * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+  }
   const uint64_t per_launch = tune.launches_per_residency <= 0
                                   ? ntiles
                                   : (uint64_t)grid * kWavesPerBlock * (uint64_t)tune.launches_per_residency;
@@ -1357,6 +1407,18 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
   }
   e = train.meet();
   if (e != hipSuccess) return e;
+  if (a.defer_list != nullptr && a.defer_cap != 0u) {
+    // the second launch: the listed rows, 64 per wave, every lane gathering its own row from the fields
+    a.perm = a.defer_list;
+    a.perm_count = a.defer_count;
+    a.perm_slots = a.defer_cap;
+    a.defer_list = nullptr;
+    a.defer_count = nullptr;
+    a.tile_begin = 0;
+    a.tile_end = ((uint64_t)a.defer_cap + kWave - 1) / kWave;
+    const int grid2 = tile_grid(kernel, lds, a.tile_end, num_cus);
+    hipLaunchKernelGGL(kernel, dim3(grid2), dim3(kBlock), lds, stream, fr, a, fr.super_heads, a.out, a.margin_out);
+  }
   return hipGetLastError();
 }
 

@@ -199,6 +199,13 @@ struct FieldsArgs {
   uint64_t tile_begin = 0, tile_end = 0;   // 64-row tiles of this launch
   int xcd_remap = 1;           // give each XCD a contiguous range of tiles
   TileShape shape;             // lanes -> gridcells of the slab
+  // rows with missing values left to a second launch, as in PredictArgs: the list holds slab rows m
+  uint32_t* defer_list = nullptr;
+  uint32_t* defer_count = nullptr;
+  uint32_t defer_cap = 0;
+  const uint32_t* perm = nullptr;        // second launch: lane l of tile t takes slab row perm[64 t + l]
+  const uint32_t* perm_count = nullptr;
+  uint32_t perm_slots = 0;
 };
 
 // OH Run1's feature engineering and post-processing (include/ohxgb.h part 3), device pointers.

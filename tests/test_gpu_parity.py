@@ -244,6 +244,32 @@ def test_fused_fields_vs_oracle(torch_cuda, deep_model, kernel, dynamic):
     assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2       # 10**x, tolerance 2 ulp
 
 
+@pytest.mark.parametrize("rate", [2e-4, 0.02])
+def test_fused_fields_with_missing_values_left_to_the_second_launch(torch_cuda, deep_model, rate):
+    """The fused call with -999.0 and NaN in its fields and ohx_defer_missing on (forced: the slab is smaller than the
+    size from which it is the default): rows with a missing value are listed and predicted by the second launch of the
+    fields kernel through the list; at 2 % of the entries the list overflows.  Margins bit for bit."""
+    grid = synth.GRIDS["C12"]
+    pl, tropp, fields = helpers.synth_state(grid)
+    rng = np.random.default_rng(17)
+    fields = [f.copy() for f in fields]
+    for f in fields[2:]:                                  # LAT and PL stay (the slab is made from PL)
+        mask = rng.random(f.shape) < rate
+        f[mask] = np.where(rng.random(int(mask.sum())) < 0.5, np.float32(synth.XX_MISS), np.float32(np.nan))
+    oh_ref, margin_ref, k1, k2 = helpers.oracle_predict_oh(deep_model.image, pl, tropp, fields, True)
+    for setting in ("on", "off"):
+        p = oh_predict.OHPredictor()
+        p.xx_bst = capi.Booster(model_buffer=deep_model.image)
+        p.xx_bst.set_param("ohx_defer_missing", setting)
+        p.first_time = False
+        oh = np.zeros(grid, dtype=np.float32)
+        margins = []
+        assert p.predict_OH_with_XGB("unused", *grid, True, 4000.0, pl, tropp, oh_predict.OHBoostInputData(fields), oh,
+                                     mode="fused", margin_out=margins) == 0
+        assert np.array_equal(helpers.bits(margins[0]), helpers.bits(margin_ref)), setting
+        assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2
+
+
 @pytest.mark.parametrize("mode", ["compat", "fused"])
 def test_python_mirror_loads_model_file_once(torch_cuda, tmp_path, small_model, mode):
     """predict_OH_with_XGB mirror end to end, incl. ONE_TIME_SETUP and the SAVE'd booster (:242-271)."""
