@@ -100,6 +100,9 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *   "ohx_cluster"     auto | on | off : group rows of no known order by the decisions they take at the top of
  *                     the first trees before walking them ("ohx_cluster_trees", "ohx_cluster_steps",
  *                     "ohx_cluster_zorder" shape the key)
+ *   "ohx_tree_split"  auto | off | 2..10 : a batch that leaves half of the chip's wave slots empty has its trees cut
+ *                     into runs walked by different wavefronts, the leaves summed in tree order by a second launch
+ *                     (a predict on 10 000 .. 300 000 rows takes a third of the time; margins unchanged, bit for bit)
  *   "ohx_defer_missing"  auto | on | off : rows that hold missing values are predicted by a second, small launch
  *                     instead of putting their whole wavefront on the missing-aware walk (auto = batches of 262 144
  *                     rows and more)

@@ -299,6 +299,7 @@ struct BoosterObj {
   std::string symbol;                   // OHXBoosterKernelSymbol's answer
   DevBuf<uint32_t> d_roots;
   DevBuf<uint32_t> d_flags;
+  DevBuf<float> d_leaves;               // small batches (kernels.hpp PredictArgs::leaf_buf): [tile][tree][lane] leaf values
   DevBuf<uint32_t> d_defer;             // deferred rows (kernels.hpp PredictArgs::defer_list): the count, then the list
   // how many rows of the last batch held missing values (read back behind the batch, looked at before the next one)
   PinnedBuf<uint32_t> h_defer_count;
@@ -728,6 +729,13 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
   tune.grid_jm = d.grid_jm;
   tune.grid_row0 = d.grid_row0;
   a.perm = cluster_rows(b, d, a, pred_leaf, kind, stream);
+  // a small batch: room for the leaves of its trees, so that they can be walked by several waves per tile
+  if (tune.tree_split != 0 && !pred_leaf && a.perm == nullptr && b.super_ok && d.nrow <= (uint64_t)b.dev.num_cus * 20u * 64u) {
+    const size_t tiles = (size_t)(d.nrow / 32 + 256);                // bricks of which at least half hold rows
+    b.d_leaves.ensure(tiles * 64 * (size_t)(a.tree_end - a.tree_begin));
+    tune.leaf_buf = b.d_leaves.p;
+    tune.leaf_words = b.d_leaves.n;
+  }
   // rows with missing values leave for a second, small launch instead of slowing their whole wave down (big batches)
   const bool deferring = a.perm == nullptr && !pred_leaf && d.ncol == 27 && defer_prepare(b, d.nrow, tune);
   HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, tune));
@@ -1046,6 +1054,13 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     b->tune.cluster_steps = std::max(1, atoi(value));
   } else if (n == "ohx_lds_pad") {
     b->tune.lds_pad = atoi(value);
+  } else if (n == "ohx_tree_split") {
+    if (v == "auto") b->tune.tree_split = -1;
+    else if (v == "off") b->tune.tree_split = 0;
+    else {
+      b->tune.tree_split = atoi(value);
+      if (b->tune.tree_split < 2 || b->tune.tree_split > 10) throw OhxError("ohx_tree_split must be auto, off or 2..10");
+    }
   } else if (n == "ohx_defer_missing") {
     if (v != "auto" && v != "on" && v != "off") throw OhxError("ohx_defer_missing must be auto, on or off");
     b->tune.defer_missing = v == "auto" ? -1 : (v == "on" ? 1 : 0);

@@ -412,7 +412,8 @@ __device__ __forceinline__ void take_from_lanes(u32x4 (&s)[CHAINS], const u32x4 
 template <int CHAINS, bool HAS_MISSING, bool TOPS>
 __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, const SuperTreeHead* __restrict__ heads,
                                             uint32_t t0, uint32_t t1, float acc, const float* __restrict__ tile,
-                                            const char* __restrict__ first, uint32_t nfirst, uint32_t nodes_bytes) {
+                                            const char* __restrict__ first, uint32_t nfirst, uint32_t nodes_bytes,
+                                            float* __restrict__ leaf_out = nullptr) {
   if (t0 >= t1) return acc;
   // the gathers below the tree tops go through a buffer descriptor over the whole forest: 0.7 % faster than the
   // same loads as global loads (31.03 against 31.26 ms, three runs each), and an index that strays reads zeros
@@ -503,6 +504,12 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c)
       if (t + c < t1) acc += __uint_as_float(leafb[c]);
+    // trees split over waves (PredictArgs::leaf_buf): the leaves themselves, for the launch that sums them in order
+    if (leaf_out != nullptr) {
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c)
+        if (t + c < t1) leaf_out[(size_t)(t + c) * kWave] = __uint_as_float(leafb[c]);
+    }
   }
   return acc;
 }
@@ -511,7 +518,7 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 template <int FMT, int CHAINS, bool TOPS>
 __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads, uint32_t t0,
                                            uint32_t t1, const float* tile, bool wave_has_missing, const char* first,
-                                           uint32_t nfirst) {
+                                           uint32_t nfirst, float* __restrict__ leaf_out = nullptr) {
   float acc = fr.base_score;
   if constexpr (FMT == 1) {
     const __amdgpu_buffer_rsrc_t nodes = make_rsrc(fr.packed, fr.packed_bytes);
@@ -520,8 +527,8 @@ __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTr
   } else if constexpr (FMT == 2) {
     // the deep gathers go through a buffer descriptor over the forest (walk_super); the tree tops are plain loads
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.super);
-    return wave_has_missing ? walk_super<CHAINS, true, TOPS>(nodes, heads, t0, t1, acc, tile, first, nfirst, fr.super_bytes)
-                            : walk_super<CHAINS, false, TOPS>(nodes, heads, t0, t1, acc, tile, first, nfirst, fr.super_bytes);
+    return wave_has_missing ? walk_super<CHAINS, true, TOPS>(nodes, heads, t0, t1, acc, tile, first, nfirst, fr.super_bytes, leaf_out)
+                            : walk_super<CHAINS, false, TOPS>(nodes, heads, t0, t1, acc, tile, first, nfirst, fr.super_bytes, leaf_out);
   } else {
     const uint4* nodes = reinterpret_cast<const uint4*>(fr.wide);
     return wave_has_missing ? walk_wide_tile<true>(nodes, fr.roots, t0, t1, acc, tile)
@@ -649,6 +656,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
     }
     return;
   }
+  if constexpr (FMT == 2) {
+    if (a.leaf_buf != nullptr) {
+      // a small batch: work item = (run of trees, tile), tiles fastest, so that the waves of a block still walk the same
+      // trees on neighbouring tiles; every item writes its trees' leaves, combine_leaves_kernel sums them
+      const uint32_t ntree = a.tree_end - a.tree_begin;
+      const uint32_t per = ((ntree + a.tree_split - 1) / a.tree_split + (CHAINS - 1)) / CHAINS * CHAINS;
+      const uint64_t ntiles = a.tile_end - a.tile_begin, items = ntiles * a.tree_split;
+      for (uint64_t item = wave_id; item < items; item += nwaves) {
+        const uint64_t tile_id = a.tile_begin + item % ntiles;
+        const uint32_t t0 = a.tree_begin + (uint32_t)(item / ntiles) * per;
+        const uint32_t t1 = t0 + per < a.tree_end ? t0 + per : a.tree_end;
+        bool valid;
+        const uint64_t row = launch_row(a, tile_id, lane, &valid);
+        if (!__any(valid) || t0 >= t1) continue;
+        const bool lane_nan = fill_tile_rows(tile, a.rows, row, valid, a.ncol, fr.num_feature, a.missing,
+                                             missing_is_nan, a.flags);
+        float* leaves = a.leaf_buf + ((size_t)(tile_id - a.tile_begin) * ntree - a.tree_begin) * kWave + lane;
+        (void)walk_tile<FMT, CHAINS, TOPS>(fr, heads, t0, t1, tile, __any(lane_nan), first, nfirst, leaves);
+      }
+      return;
+    }
+  }
   // the second launch of a deferred-rows predict: how many slots the first one filled is only known on the device
   uint64_t slots = ~0ull, tile_end = a.tile_end;
   if (a.perm_count != nullptr) {
@@ -667,6 +696,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
     // the tile is private to this wave: its own LDS writes are ordered before its reads
     const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
     if (valid) __builtin_nontemporal_store(acc, out + row);
+  }
+}
+
+// The second launch of a small batch (PredictArgs::leaf_buf): one wave per tile, margin = ((base + leaf_0) + leaf_1) + ...
+__global__ __launch_bounds__(kBlock) void combine_leaves_kernel(PredictArgs a, float base_score, float* __restrict__ out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint64_t ntiles = a.tile_end - a.tile_begin, nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  const uint32_t ntree = a.tree_end - a.tree_begin;
+  for (uint64_t w = (uint64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave; w < ntiles; w += nwaves) {
+    bool valid;
+    const uint64_t row = launch_row(a, a.tile_begin + w, lane, &valid);
+    if (!__any(valid)) continue;
+    const float* leaves = a.leaf_buf + (size_t)w * ntree * kWave + lane;
+    float acc = base_score;
+#pragma unroll 4
+    for (uint32_t t = 0; t < ntree; ++t) acc += leaves[(size_t)t * kWave];
+    if (valid) out[row] = acc;
   }
 }
 
@@ -1202,14 +1248,8 @@ struct TrainCursor {
   }
 };
 
-// One launch, or a train of launches of one residency (grid x 4 tiles) each.
-template <class K>
-hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, PredictArgs a, int num_cus,
-                             hipStream_t stream, const LaunchTuning& tune) {
-  lds += (size_t)tune.lds_pad;
-  hipError_t e = ensure_lds(kernel, lds);
-  if (e != hipSuccess) return e;
-  // bricks when the caller named the grid the rows come from
+// which rows a wave takes: bricks when the caller named the grid the rows come from
+void shape_rows(PredictArgs& a, const LaunchTuning& tune) {
   if (a.perm == nullptr && tune.grid_im > 0 && tune.grid_jm > 0 && a.nrow > 0 &&
       (tune.brick_li < 0 || tune.brick_li + tune.brick_lj + tune.brick_lk == 6)) {
     if (tune.brick_li < 0) a.shape.set_grid_auto((uint32_t)tune.grid_im, (uint32_t)tune.grid_jm, tune.grid_row0, a.nrow);
@@ -1218,6 +1258,37 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
     a.shape.k_fastest = (uint32_t)tune.brick_k_fastest;
   }
   if (a.shape.ntiles(a.nrow) >= 0xFFFFFFFFull) a.shape = TileShape();   // tile_row numbers bricks in 32 bits
+}
+
+// A small batch: the trees in `split` runs, a wave per (run, tile), then the launch that sums the leaves in tree order.
+template <class K>
+hipError_t launch_rows_split(K kernel, size_t lds, const DeviceForest& fr, PredictArgs a, int num_cus, hipStream_t stream,
+                             const LaunchTuning& tune, uint32_t split) {
+  hipError_t e = ensure_lds(kernel, lds);
+  if (e != hipSuccess) return e;
+  a.xcd_remap = tune.xcd_remap;
+  a.run_log = 0;
+  a.run_lo_bits = 0;
+  a.tile_begin = 0;
+  a.tile_end = a.shape.ntiles(a.nrow);
+  a.leaf_buf = tune.leaf_buf;
+  a.tree_split = split;
+  const int grid = tile_grid(kernel, lds, a.tile_end * split, num_cus);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, fr, a, fr.super_heads, a.out);
+  const uint64_t blocks = (a.tile_end + kWavesPerBlock - 1) / kWavesPerBlock;
+  hipLaunchKernelGGL(combine_leaves_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0, stream, a,
+                     fr.base_score, a.out);
+  return hipGetLastError();
+}
+
+// One launch, or a train of launches of one residency (grid x 4 tiles) each.
+template <class K>
+hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, PredictArgs a, int num_cus,
+                             hipStream_t stream, const LaunchTuning& tune) {
+  lds += (size_t)tune.lds_pad;
+  hipError_t e = ensure_lds(kernel, lds);
+  if (e != hipSuccess) return e;
+  shape_rows(a, tune);
   const uint64_t ntiles = a.shape.ntiles(a.nrow);
   const int grid = tile_grid(kernel, lds, ntiles, num_cus);
   a.xcd_remap = tune.xcd_remap;
@@ -1324,8 +1395,30 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
     if (e == hipSuccess && listing) e = hipMemsetAsync(a.defer_list, 0xFF, (size_t)a.defer_cap * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
   }
+  // A small batch leaves most of the chip's wave slots empty and takes as long as one tile's walk of ALL trees
+  // (165 us for the OH booster whatever N, profiles/r03_latency_rows.json): cut the trees into runs walked by
+  // different waves.  Decided on the live tiles of the batch against the chip's 20 waves per CU.
+  uint32_t split = 0;
+  if (is_super && a.perm == nullptr && tune.tree_split != 0 && tune.leaf_buf != nullptr && a.tree_end - a.tree_begin >= 8) {
+    PredictArgs probe = a;
+    shape_rows(probe, tune);
+    // bricks laid over a level of which the batch holds a small part are mostly empty: 64 consecutive rows per wave then
+    if (probe.shape.im != 0 && probe.shape.live_tiles() * 2 < probe.shape.ntiles(a.nrow)) probe.shape = TileShape();
+    const uint64_t ntiles = probe.shape.ntiles(a.nrow);
+    const uint64_t live = probe.shape.im != 0 && probe.shape.live_tiles() < ntiles ? probe.shape.live_tiles() : ntiles;
+    const uint64_t slots = (uint64_t)num_cus * 20u;
+    const uint32_t ntree = a.tree_end - a.tree_begin;
+    uint64_t want = tune.tree_split > 1 ? (uint64_t)tune.tree_split : (live * 2 <= slots ? slots / (live ? live : 1) : 0);
+    if (want > 10) want = 10;
+    if (want * 4 > ntree) want = ntree / 4;
+    if (want >= 2 && ntiles * ntree * kWave <= tune.leaf_words) {
+      split = (uint32_t)want;
+      a.shape = probe.shape;
+    }
+  }
 #define OHX_ROWS_T(FMT, CH, TOPS)                                                                                  \
   {                                                                                                                \
+    if (split) return launch_rows_split(predict_rows_tile_kernel<FMT, CH, false, TOPS>, lds, fr, a, num_cus, stream, tune, split); \
     hipError_t e_ = pf ? launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, true, TOPS>, lds, fr, a, num_cus, stream, tune)   \
                        : launch_rows_tiled(predict_rows_tile_kernel<FMT, CH, false, TOPS>, lds, fr, a, num_cus, stream, tune); \
     if (e_ == hipSuccess && listing)                                                                               \

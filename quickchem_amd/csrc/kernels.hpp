@@ -128,6 +128,12 @@ struct PredictArgs {
   uint32_t* defer_list = nullptr;
   uint32_t* defer_count = nullptr;
   uint32_t defer_cap = 0;
+  // Small batches (fewer tiles than the chip has wave slots): the trees are cut into tree_split runs and a tile is
+  // walked by tree_split waves, one per run, each writing its trees' LEAF VALUES to leaf_buf[(tile * ntree + t) * 64 +
+  // lane]; a second launch adds them up in tree order (float32 addition is not associative: partial sums would not
+  // give the margin of the sequential sum).  Latency of a predict: that of 100 / tree_split trees.
+  float* leaf_buf = nullptr;
+  uint32_t tree_split = 1;
   // 27-column rows of a tile fetched by the wave together, run of consecutive rows by run (kernels.hip RowPieces):
   // log2 of the rows per run (0 = every lane fetches its own row), and where a run's rows sit among the lanes
   uint32_t run_log = 0, run_lo_bits = 0;
@@ -157,6 +163,11 @@ struct LaunchTuning {
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
   int coop_rows = 1;  // ... fetched by the wave together where a tile is made of runs of >= 4 consecutive rows
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
+  // small batches: trees split over several waves per tile (PredictArgs::leaf_buf): -1 = when the batch leaves half of
+  // the chip's wave slots empty, 0 = never, n > 1 = always in n runs; needs the booster's leaf buffer
+  int tree_split = -1;
+  float* leaf_buf = nullptr;
+  size_t leaf_words = 0;
   // rows with missing values go to a list and a second small launch (PredictArgs::defer_list) instead of slowing
   // their whole wave down for every tree: -1 = for batches of 262 144 rows and more, 0 = never, 1 = always;
   // needs the booster's list buffer (defer_words words: the count, then the list)

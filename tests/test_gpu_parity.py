@@ -122,6 +122,23 @@ def test_deferred_rows_by_default_on_a_big_batch(torch_cuda, small_model):
     assert np.array_equal(helpers.bits(got), helpers.bits(want))
 
 
+@pytest.mark.parametrize("kernel", ["super1", "super2", "super4"])
+def test_small_batches_with_their_trees_split_over_waves(torch_cuda, deep_model, kernel):
+    """ohx_tree_split: a batch that leaves the chip's wave slots mostly empty has its trees cut into runs walked by
+    different waves; a second launch sums the leaves in tree order, so the margins are the sequential sum's, bit for
+    bit - whatever the number of runs, with a tree limit that does not divide by it, with missing values, with and
+    without a grid hint (bricks, or 64 consecutive rows when the bricks of the hint would be mostly empty)."""
+    grid = (96, 72, 72)
+    rows = with_missing(synth.rows_cpu(grid, 500, 96 * 72 * 3 + 333), 0.003, seed=21)
+    for lim in (0, 37):
+        want = helpers.oracle_predict(deep_model.image, rows, synth.XX_MISS, ntree_limit=lim)
+        for split in ("off", "auto", "2", "3", "7", "10"):
+            for hint in ((96, 72, 500), (0, 0, 0), (360, 2160, 500)):
+                got = gpu_predict(deep_model.image, rows, synth.XX_MISS, kernel, ntree_limit=lim,
+                                  params={"ohx_tree_split": split}, grid=hint)
+                assert np.array_equal(helpers.bits(got), helpers.bits(want)), (lim, split, hint)
+
+
 @pytest.mark.parametrize("kernel", ["wide", "packed4", "super2"])
 def test_ntree_limit_and_leaf_indices(torch_cuda, small_model, kernel):
     rows = with_missing(synth.rows_cpu(synth.GRIDS["C12"], 0, 3000), 0.005)
