@@ -44,6 +44,8 @@ def child(args):
     im, jm_all, km = grid
     parts = 8 * args.nranks
     jm = jm_all // parts
+    if args.block:                                        # a GEOS-sized rank block instead: im x jm columns, all levels
+        im, jm = args.block
     sub = (im, jm, km)
     n = im * jm * km
     # the rank's block, pageable host memory: the reference's xx_carr rows, and the same block as 27 SoA fields
@@ -105,7 +107,7 @@ def parent(args):
     model = synth.make_model()
     path = os.path.join(tmp, "oh.model")
     open(path, "wb").write(bytes(model.image))
-    result = {"grid": args.grid, "model_file_bytes": os.path.getsize(path), "ticks": args.ticks,
+    result = {"grid": args.grid, "block": args.block, "model_file_bytes": os.path.getsize(path), "ticks": args.ticks,
               "note": "P processes on one GPU, each a rank owning C360/(8P) gridcells in pageable host arrays; "
                       "aggregate = the gridcells of the ticks that end inside the interval in which every rank is "
                       "past its first tick and none has finished, over that interval",
@@ -117,6 +119,8 @@ def parent(args):
         for r in range(P):
             cmd = [sys.executable, os.path.abspath(__file__), "--child", "--rank", str(r), "--nranks", str(P), "--model", path,
                    "--grid", args.grid, "--ticks", str(args.ticks), "--start-at", repr(start_at), "--hold-until", repr(hold_until)]
+            if args.block:
+                cmd += ["--block", "%d,%d" % tuple(args.block)]
             procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         ranks = []
         for p in procs:                                     # children hold their memory until killed below
@@ -158,6 +162,7 @@ def main():
     ap.add_argument("--grid", default="C360")
     ap.add_argument("--ticks", type=int, default=100)
     ap.add_argument("--prep-s", type=float, default=60.0, help="time the ranks get to build their host arrays before the common start")
+    ap.add_argument("--block", default="", help="im,jm: every rank owns an (im, jm, 72) block of its own instead of C360/(8P)")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--nranks", type=int, default=1)
@@ -165,6 +170,7 @@ def main():
     ap.add_argument("--start-at", type=float, default=0.0)
     ap.add_argument("--hold-until", type=float, default=0.0)
     args = ap.parse_args()
+    args.block = [int(x) for x in args.block.split(",")] if args.block else None
     if args.child:
         return child(args)
     args.ranks = [int(x) for x in args.ranks.split(",")]
