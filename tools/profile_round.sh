@@ -13,7 +13,7 @@ grep "^{\"metric\"" $O/bench_under_rocprof.log | tail -1 > $O/bench.json
 cp $O/trace/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 timeout -k 10 600 python3 bench.py > $O/bench_plain.log 2>&1
 grep "^{\"metric\"" $O/bench_plain.log | tail -1 > $O/bench_plain.json
-PMC_KERNEL=predict_rows_tile_kernel tools/pmc.sh $tag > /dev/null 2>&1
+PMC_KERNEL='predict_rows_tile_kernel<2, 2, true, true>' tools/pmc.sh $tag > /dev/null 2>&1
 cp gpurun_out/pmc_$tag/summary.txt $O/pmc_summary.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/calib_$c -- python3 bench.py --cpu-seconds 0 --no-verify --steps 2 --warmup 1 --trees 1 --depth 0 > $O/calib_$c.log 2>&1
@@ -26,7 +26,7 @@ with open(O + '/calib_fetch_write.txt', 'w') as out:
         tot = 0.0
         for f in glob.glob(f'{O}/calib_{c}/*/*_counter_collection.csv'):
             for r in csv.DictReader(open(f)):
-                if 'predict_' in r['Kernel_Name'] and r['Counter_Name'] == c:
+                if 'predict_rows_tile_kernel<2, 2, true' in r['Kernel_Name'] and r['Counter_Name'] == c:
                     tot += float(r['Counter_Value'])
         line = f"{c} per_step={tot/3:.6g} (1 tree of depth 0: rows 6 046 617 600 B read, 223 948 800 B written per step)"
         print(line); out.write(line + "\n")
