@@ -15,7 +15,7 @@ module ohx_bindings
    public :: XGDMatrixCreateFromMat, XGDMatrixFree, XGDMatrixNumRow, XGDMatrixNumCol
    public :: XGBoosterCreate, XGBoosterFree, XGBoosterLoadModel, XGBoosterSaveModel
    public :: XGBoosterPredict, XGBoosterSetParam, OHXBoosterPredictFields, OHXDMatrixSetGrid
-   public :: OHXCommGetUniqueId, OHXCommInitRank, OHXCommFree, OHXShardRows, OHXAllGatherOH, OHX_UNIQUE_ID_BYTES
+   public :: OHXCommGetUniqueId, OHXCommInitRank, OHXCommFree, OHXCommInfo, OHXShardRows, OHXAllGatherOH, OHX_UNIQUE_ID_BYTES
    public :: ohx_last_error, ohx_c_string
 
    integer, parameter :: OHX_UNIQUE_ID_BYTES = 128
@@ -150,6 +150,12 @@ module ohx_bindings
          import :: c_int, c_ptr
          type(c_ptr), value :: comm
          integer(c_int)     :: rc
+      end function
+
+      function OHXCommInfo(rccl_version) bind(C, name="OHXCommInfo") result(rc)
+         import :: c_int
+         integer(c_int), intent(out) :: rccl_version
+         integer(c_int)              :: rc
       end function
 
       function OHXShardRows(nrows_total, nranks, rank, row0, nrows) bind(C, name="OHXShardRows") result(rc)
