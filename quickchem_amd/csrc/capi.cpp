@@ -730,7 +730,8 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
   tune.grid_row0 = d.grid_row0;
   a.perm = cluster_rows(b, d, a, pred_leaf, kind, stream);
   // a small batch: room for the leaves of its trees, so that they can be walked by several waves per tile
-  if (tune.tree_split != 0 && !pred_leaf && a.perm == nullptr && b.super_ok && d.nrow <= (uint64_t)b.dev.num_cus * 20u * 64u) {
+  // (only batches that can qualify: their tiles fill at most half of the chip's 20 waves per CU)
+  if (tune.tree_split != 0 && !pred_leaf && a.perm == nullptr && b.super_ok && d.nrow <= (uint64_t)b.dev.num_cus * 10u * 64u + 4096u) {
     const size_t tiles = (size_t)(d.nrow / 32 + 256);                // bricks of which at least half hold rows
     b.d_leaves.ensure(tiles * 64 * (size_t)(a.tree_end - a.tree_begin));
     tune.leaf_buf = b.d_leaves.p;
