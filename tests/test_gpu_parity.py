@@ -679,6 +679,40 @@ def test_rows_fetched_together_or_lane_by_lane(torch_cuda, shape, small_model):
                     b.free()
 
 
+def test_two_oh_instances_from_two_threads(torch_cuda, small_model, deep_model):
+    """QuickChem_GridComp.rc may list several OH instances (:22); a host that drives two of them from two threads has two
+    boosters in one process.  Each thread runs the reference's five calls ten times on its own booster and its own
+    rows (ctypes releases the GIL during the calls); the library's process-wide pools and caches - parked matrix
+    buffers, the inf-check scratch, the level-size verdicts - are shared between them.  Every result against the
+    oracle."""
+    import threading
+    grid = (96, 72, 72)
+    jobs = []
+    for k, model in enumerate((small_model, deep_model)):
+        rows = with_missing(synth.rows_cpu(grid, 1000 * k, 96 * 72 * (3 + k)), 0.001, seed=30 + k)
+        jobs.append((model.image, rows, helpers.oracle_predict(model.image, rows, synth.XX_MISS)))
+    errors = []
+
+    def run(image, rows, want):
+        try:
+            b = capi.Booster(model_buffer=image)
+            for _ in range(10):
+                d = capi.DMatrix(rows, missing=synth.XX_MISS)
+                got = b.predict(d)
+                d.free()
+                if not np.array_equal(helpers.bits(got), helpers.bits(want)):
+                    errors.append("margins differ")
+            b.free()
+        except Exception as e:                      # noqa: BLE001 - reported by the assert below
+            errors.append(repr(e))
+    threads = [threading.Thread(target=run, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
+
+
 def test_random_grids_shards_and_brick_shapes(torch_cuda):
     """tools/fuzz_tiles.py: random grids, shards, brick shapes, lane orders and launch shapes on device buffers of
     exactly nrow x 27 floats, against the oracle."""

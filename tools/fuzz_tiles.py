@@ -39,7 +39,10 @@ def run(cases, seed):
         out = torch.full((m,), 7.0, dtype=torch.float32, device="cuda:0")
         params = {"ohx_brick": bricks[int(rng.integers(0, len(bricks)))], "ohx_brick_k_fastest": str(int(rng.integers(0, 2))),
                   "ohx_coop_rows": "1" if rng.random() < 0.8 else "0", "ohx_tree_tops": ["auto", "on", "off"][int(rng.integers(0, 3))],
-                  "ohx_launches_per_residency": str(int(rng.integers(0, 4)))}
+                  "ohx_launches_per_residency": str(int(rng.integers(0, 4))),
+                  # round 3: small batches with their trees split over waves, rows with missing values left to a second launch
+                  "ohx_tree_split": ["auto", "off", "2", "3", "5"][int(rng.integers(0, 5))],
+                  "ohx_defer_missing": ["auto", "on", "off"][int(rng.integers(0, 3))]}
         b = capi.Booster(model_buffer=image)
         for k, v in params.items():
             if not (k == "ohx_brick" and v == "auto"):
