@@ -133,6 +133,34 @@ def test_whole_c360_batch_against_the_oracle_row_for_row(full_model):
         print(f"levels {k}-{k + 7}: {z - a} margins equal the oracle's, {time.time() - t0:.0f} s", flush=True)
 
 
+@pytest.mark.parametrize("grid", [(180, 1080, 72), (183, 541, 72)])
+def test_oh_run1_at_c180_against_the_oracle(full_model, grid):
+    """The call the GridComp shell makes every tick (OHXBoosterRun1: engineered features, k-slab, fused gather +
+    walk in a train of launches, tropopause mask, unit conversion; OH_GridCompMod.F90:1444-1488,275-374,1557-1595) on a
+    whole C180 L72 state with the 100-tree depth-18 booster, and on a grid no side of which is a multiple of the brick,
+    every gridcell against the CPU restatement: NDWET and the masked cells bit for bit, OH within 3 ulp (10**x)."""
+    st = helpers.run1_state(grid, seed=grid[0])
+    lib = helpers.oracle_lib()
+    ob = capi.Booster(model_buffer=full_model.image, lib=lib)
+    want = ob.run1(st, dynamic_k_range=True)
+    ob.free()
+    b = capi.Booster(model_buffer=full_model.image)
+    got = b.run1(st, dynamic_k_range=True)
+    again = b.run1(st, dynamic_k_range=True)                   # second tick: parked buffers, the deferral's history
+    b.free()
+    assert (got["k1"], got["k2"]) == (want["k1"], want["k2"]) and got["k1"] > 1
+    assert np.array_equal(helpers.bits(got["ndwet"]), helpers.bits(want["ndwet"]))
+    k1 = got["k1"]
+    assert not got["oh_boost"][:, :, :k1 - 1].any()
+    assert helpers.ulp_diff(got["oh_boost"][:, :, k1 - 1:], want["oh_boost"][:, :, k1 - 1:]).max() <= 2
+    pl = (st["ple_mod"][:, :, :-1] + st["ple_mod"][:, :, 1:]) * np.float32(0.5)
+    above = ~(pl > st["tropp_mod"][:, :, None])
+    assert np.array_equal(helpers.bits(got["oh"][above]), helpers.bits(want["oh"][above]))
+    assert helpers.ulp_diff(got["oh"][~above], want["oh"][~above]).max() <= 3
+    for name in ("oh", "oh_boost", "ndwet"):
+        assert np.array_equal(helpers.bits(again[name]), helpers.bits(got[name])), name
+
+
 def test_c720_l137_shard_starting_inside_a_level(full_model):
     """Config #5 with the hint and a ragged start: one eighth of C720 L137 whose first row is 12 345 cells into
     a level (row0 not a multiple of im*jm), so the first and last bricks overhang the row range."""
