@@ -445,15 +445,61 @@ def bench_fields(args, grid, n_total, model, booster, dev, t_model):
         "cpu_baseline": None}), flush=True)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_argv(ngpus, argv, port):
+    """The command `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) turns itself into: N fresh
+    rank processes under torch.distributed.run on this node, rendezvous on 127.0.0.1, every rank running this very
+    file with the caller's own arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started plainly (the way --gpus 1 is): start the N ranks as CHILD processes and pass
+    on rank 0's JSON line and their return code.  Nothing in this process has touched the GPU (importing torch does
+    not; torch.cuda.device_count() does not on this image), and nothing here replaces it (no exec): the children are
+    fresh interpreters, one per GPU."""
+    import subprocess
+    share = os.environ.get("OHX_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        raise SystemExit(f"bench: --gpus {args.gpus} but this node shows {have} GPU(s)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    for k in ("RANK", "LOCAL_RANK", "MASTER_PORT"):          # a stale one would send the ranks elsewhere
+        env.pop(k, None)
+    cmd = launcher_argv(args.gpus, sys.argv[1:], free_port())
+    print("bench: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = 0
+    for ln in proc.stdout:                                   # the ranks' stderr goes straight through
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+        lines += ln.startswith("{")
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench: the ranks ended with rc 0 but printed {lines} JSON lines", file=sys.stderr)
+        rc = 1
+    raise SystemExit(rc)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world} (start `python bench.py --gpus N` plainly, or under "
+                         f"python -m torch.distributed.run --nproc-per-node N)")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     # rehearsal of the multi-rank path on a one-GPU box: OHX_BENCH_SHARE_GPU=1 puts every rank on device 0
     # (RCCL refuses two ranks on one device, so OHX_BENCH_BACKEND=gloo goes with it); never for numbers

@@ -106,3 +106,32 @@ def test_two_ranks_reassemble_the_field(tmp_path, small_model, n_total):
     for r in range(2):
         got = np.load(tmp_path / f"rank{r}.npy")
         assert np.array_equal(helpers.bits(got), helpers.bits(want))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` is how the driver runs every N: with N > 1 and no WORLD_SIZE the process must turn
+    into a launcher of N fresh rank processes (never an exec, never after a GPU call), with the caller's own
+    arguments; under torch.distributed.run (WORLD_SIZE set) it must be a rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    argv = bench.launcher_argv(4, ["--gpus", "4", "--steps", "7", "--warmup", "2"], 29999)
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "4" and "--nnodes=1" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29999"
+    at = argv.index(os.path.join(root, "bench.py"))
+    assert argv[at + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]      # the ranks see what the caller said
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src
+    # no GPU here: the launcher says so before starting anything (and not the old "launch with: ..." refusal)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "this node shows" in r.stderr and "launch with" not in r.stderr
+    # as a rank of another world size it refuses, naming both ways to start it
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr

@@ -210,18 +210,20 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OHX_BENCH_SHARE_GPU="1", OHX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    # started plainly, the way the driver starts every N: bench.py launches its two ranks itself
+    plain = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     for extra in ([], ["--gather-chunks", "1"]):
-        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                            "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(root, "bench.py"),
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"),
                             "--gpus", "2", "--grid", "C90", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
-                            "--verify"] + extra, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+                            "--verify"] + extra, capture_output=True, text=True, env=plain, timeout=900, cwd=root)
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["config"]["verified"] is True and line["n_gpus"] == 2 and line["config"]["grid_hint"] is True
         assert line["phases"]["even_shards"] is True and line["phases"]["gather_bytes_total"] == 4 * 90 * 540 * 72
         assert line["phases"]["predict_ms"] > 0 and len(line["distributed"]["ranks"]) == 2
-    # ragged shards (an odd number of rows over two ranks: the fixed-slot gather and its compaction), and the
-    # predict-only control that a scaling curve is split with
+    # under torch.distributed.run (the other way to start it): ragged shards (an odd number of rows over two ranks:
+    # the fixed-slot gather and its compaction), and the predict-only control that a scaling curve is split with
     for extra in (["--rows", "995327"], ["--gather", "none"]):
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                             "--master-addr", "127.0.0.1", "--master-port", "29578", os.path.join(root, "bench.py"),
