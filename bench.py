@@ -680,7 +680,11 @@ def main():
         kernel_s = float(t.item())
 
     info = booster.info()
-    launches_per_step = sum(-(-((hi - lo + 63) // 64) // (256 * 20 * 2)) for lo, hi in pieces)  # per 2 residencies
+    symbol = booster.kernel_symbol(27)
+    # tiles per launch: the ring kernel takes 8 rounds of one 16-wave block per CU, the tile kernel 2 of 20 waves per CU
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    per_launch = cus * 16 * 8 if "ring" in symbol else cus * 20 * 2
+    launches_per_step = sum(-(-((hi - lo + 63) // 64) // per_launch) for lo, hi in pieces)
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total / (elapsed / args.steps)
     algo_bytes = BYTES_PER_CELL * n_local + info["node_bytes"]
@@ -741,7 +745,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "measured_frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "kernel": booster.kernel_symbol(27), "kernel_ms": kernel_s * 1e3,
+                         "kernel": symbol, "kernel_ms": kernel_s * 1e3,
                          "per": "step = the train of launches of one pass over the batch",
                          "launches_per_step": launches_per_step,
                          "avg_launch_us": kernel_s * 1e6 / launches_per_step,

@@ -293,7 +293,7 @@ struct BoosterObj {
   DevBuf<SuperTreeHead> d_super_heads;
   bool super_ok = false;
   uint64_t super_slots = 0;
-  uint64_t super_gathers[2] = {0, 0};   // vector-memory instructions a wave issues to walk the whole forest once
+  uint64_t super_gathers[3] = {0, 0, 0};   // vector-memory instructions a wave issues to walk the whole forest once
                                         // without / with tree tops
   double super_mean_steps = 0.0;
   std::string symbol;                   // OHXBoosterKernelSymbol's answer
@@ -336,6 +336,11 @@ BoosterObj* as_booster(BoosterHandle h) {
   return static_cast<BoosterObj*>(h);
 }
 
+// Tree tops (and the ring kernels) pay where the texture addresser is the bound: deep trees.  Measured on the MI355X
+// with the OH recipe's boosters (profiles/r02_sweeps.txt): 9 steps per tree (depth 18) 3.4 % faster with tops, 5 steps
+// (depth 10) 10 % slower, 3 steps (depth 6) 27 % slower.
+constexpr double kTreeTopsMinMeanSteps = 7.0;
+
 KernelKind pick_kernel(const BoosterObj& b) {
   const std::string& k = b.kernel_name;
   if (k == "wide") return KernelKind::Wide;
@@ -343,6 +348,10 @@ KernelKind pick_kernel(const BoosterObj& b) {
     if (k == "super1") return KernelKind::Super1;
     if (k == "super3") return KernelKind::Super3;
     if (k == "super4") return KernelKind::Super4;
+    // deep forests walk fastest with their tree tops resident in LDS (kernels.hip, the ring kernels): 12 % on the OH
+    // booster (9 steps per tree), 3 % at 7 steps, 8 % SLOWER at 5 (profiles/r04_sweeps.txt) - same bar as the tree tops
+    if (k == "ring" || (k == "auto" && b.forest.num_feature == 27 && b.super_mean_steps >= kTreeTopsMinMeanSteps))
+      return KernelKind::Ring;
     if (k == "super2" || k == "auto") return KernelKind::Super2;
   }
   if (!b.packed_ok) return KernelKind::Wide;
@@ -355,19 +364,18 @@ KernelKind pick_kernel(const BoosterObj& b) {
 // one coalesced load of its top (steps 1-3) and one gather for every step after the third, of at least four
 // steps.  Without: a gather per step, less the first step of the trees whose start nodes sit in the kernels'
 // LDS table.
-uint64_t count_super_gathers(const SuperForest& sf, bool tops) {
+uint64_t count_super_gathers(const SuperForest& sf, int mode) {   // 0 plain walk, 1 tree tops, 2 ring kernels
   uint64_t n = 0;
   for (size_t t = 0; t < sf.heads.size(); ++t) {
     const uint32_t steps = sf.heads[t].steps;
-    n += tops ? (steps < 4u ? 4u : steps) - 2u : steps - (t < kFirstStepTrees && steps ? 1u : 0u);
+    if (mode == 2) n += (steps < 4u ? 4u : steps) - 4u;        // steps 1-4 from LDS
+    else n += mode == 1 ? (steps < 4u ? 4u : steps) - 2u : steps - (t < kFirstStepTrees && steps ? 1u : 0u);
   }
+  // ring: a group of four trees is staged with 11 wave loads, once per block of 16 waves
+  if (mode == 2) n += (sf.heads.size() * 11 + 63) / 64;
   return n;
 }
 
-// Tree tops pay where the texture addresser is the bound: deep trees.  Measured on the MI355X with the OH
-// recipe's boosters (profiles/r02_sweeps.txt): 9 steps per tree (depth 18) 3.4 % faster with, 5 steps (depth 10)
-// 10 % slower, 3 steps (depth 6) 27 % slower.
-constexpr double kTreeTopsMinMeanSteps = 7.0;
 double mean_super_steps(const SuperForest& sf) {
   double n = 0;
   for (const SuperTreeHead& h : sf.heads) n += h.steps;
@@ -377,7 +385,9 @@ bool use_tree_tops(const LaunchTuning& tune, double mean_steps) {
   return tune.tree_tops < 0 ? mean_steps >= kTreeTopsMinMeanSteps : tune.tree_tops != 0;
 }
 
-bool wants_super(const std::string& k) { return k == "auto" || (k.size() == 6 && k.compare(0, 5, "super") == 0); }
+bool wants_super(const std::string& k) {
+  return k == "auto" || k == "ring" || (k.size() == 6 && k.compare(0, 5, "super") == 0);
+}
 
 void invalidate_device_state(BoosterObj& b) {
   b.uploaded = false;
@@ -410,8 +420,9 @@ void ensure_uploaded(BoosterObj& b) {
     b.super_ok = emit_super(b.forest, &sf) && sf.nodes.size() * sizeof(SuperNode) < 0xFFFFFFF0ull;
     if (b.super_ok) {
       b.super_slots = sf.nodes.size();
-      b.super_gathers[0] = count_super_gathers(sf, false);
-      b.super_gathers[1] = count_super_gathers(sf, true);
+      b.super_gathers[0] = count_super_gathers(sf, 0);
+      b.super_gathers[1] = count_super_gathers(sf, 1);
+      b.super_gathers[2] = count_super_gathers(sf, 2);
       b.super_mean_steps = mean_super_steps(sf);
       b.d_super.upload(sf.nodes);
       b.d_super_heads.upload(sf.heads);
@@ -996,8 +1007,8 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
   const std::string n(name), v(value);
   if (n == "ohx_kernel") {
     if (v != "auto" && v != "wide" && v != "packed1" && v != "packed2" && v != "packed4" && v != "super1" &&
-        v != "super2" && v != "super3" && v != "super4")
-      throw OhxError("ohx_kernel must be one of auto, wide, packed1, packed2, packed4, super1 .. super4");
+        v != "super2" && v != "super3" && v != "super4" && v != "ring")
+      throw OhxError("ohx_kernel must be one of auto, wide, packed1, packed2, packed4, super1 .. super4, ring");
     if (v != b->kernel_name) invalidate_device_state(*b);
     b->kernel_name = v;
   } else if (n == "ohx_top_levels") {
@@ -1055,6 +1066,9 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     b->tune.cluster_steps = std::max(1, atoi(value));
   } else if (n == "ohx_lds_pad") {
     b->tune.lds_pad = atoi(value);
+  } else if (n == "ohx_ring_rounds") {
+    b->tune.ring_rounds = atoi(value);
+    if (b->tune.ring_rounds < 0) throw OhxError("ohx_ring_rounds must be >= 0");
   } else if (n == "ohx_tree_split") {
     if (v == "auto") b->tune.tree_split = -1;
     else if (v == "off") b->tune.tree_split = 0;
@@ -1567,7 +1581,13 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
   const bool packed_used = packed_ok && b->kernel_name != "wide";
   bool super_used = false;
   uint64_t super_slots = b->super_slots;
-  uint64_t super_gathers = b->super_gathers[use_tree_tops(b->tune, b->super_mean_steps) ? 1 : 0];
+  // (the ring kernels where the booster's big batches go through them: pick_kernel)
+  auto walk_mode = [&](double mean_steps) {
+    const bool ring = b->kernel_name == "ring" ||
+                      (b->kernel_name == "auto" && b->forest.num_feature == 27 && mean_steps >= kTreeTopsMinMeanSteps);
+    return ring ? 2 : (use_tree_tops(b->tune, mean_steps) ? 1 : 0);
+  };
+  uint64_t super_gathers = b->super_gathers[walk_mode(b->super_mean_steps)];
   if (wants_super(b->kernel_name)) {
     if (b->uploaded) {
       super_used = b->super_ok;
@@ -1575,7 +1595,7 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
       SuperForest sf;
       super_used = emit_super(b->forest, &sf);
       super_slots = sf.nodes.size();
-      super_gathers = count_super_gathers(sf, use_tree_tops(b->tune, mean_super_steps(sf)));
+      super_gathers = count_super_gathers(sf, walk_mode(mean_super_steps(sf)));
     }
   }
   info[0] = b->forest.trees.size();

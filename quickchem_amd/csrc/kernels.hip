@@ -36,6 +36,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // into LDS whose origin the compiler loses track of goes through the texture addresser like a global load)
 typedef const __attribute__((address_space(3))) char* lds_cptr;
 typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 // The packed 8-byte nodes are read through a buffer descriptor: one 64-bit load per node that the
 // compiler cannot split into dword loads (it does split a plain uint2 load when only one half
@@ -699,6 +701,406 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   }
 }
 
+// ------------------------------------------------------------------ tree tops resident in LDS: the ring kernels
+//
+// The tile kernels above pay the texture addresser ~25 cycles for every vector-memory instruction and a
+// wave issues seven per tree.  A `ds_read_b128` whose lanes ask for a handful of distinct records costs the LDS 4-8
+// cycles (MI355X_MICROARCH.md §LDS: four groups of 16 lanes, a cycle each when the records differ in banks or are
+// the same).  The ring kernels keep the records of a walk's first FOUR steps - breadth first they are a tree's first
+// 176 (4 fillers + 4 + 8 + 32 + 128; emit_super) - in LDS for the trees being walked, and only steps 5 .. 9 go through
+// the addresser: 5 gathers + 0.17 staging loads per wave and tree, against 6 gathers + 1 tree top.
+//
+// LDS cannot hold that for every wave's own trees, so the 16 waves of a block (1 024 threads, 16 tiles = 110.6 KB, one
+// block per CU) walk the SAME trees at about the same time, in groups of four (four chains per lane: with 16 waves
+// instead of 20 the walk needs them to keep the addresser busy): a ring of four buffers of 4 x 176 records (44 KB).
+// With a barrier per group every wave would wait for the slowest of the block, group after group: measured, that
+// costs all the gain and more (32.8 ms against 26.7 with the barriers taken out, 31.1 for the tile kernel;
+// profiles/r04_sweeps.txt).  So the waves only meet through three kinds of words in LDS:
+//   progress[w]  groups wave w is done with (written by w)
+//   claim        next group nobody has started to stage (compare-and-swap by the first wave to reach the group before)
+//   filled       groups that are complete in the ring (written by their stager)
+// The wave that is first at group g stages group g + 1: `buffer_load ... lds` straight into the ring (no registers, no
+// ds_write), once every wave is done with the group whose buffer that is (g + 1 - 4); it then walks group g like
+// everybody else and publishes g + 1 from inside that walk, behind the LDS steps, when its DMA has had their time to
+// land.  Nobody waits for anybody unless it is two groups ahead of the slowest wave or its next group has not landed.
+// Every wait is on work with a lower group number, so the waves cannot wait in a circle; the spins are bounded all the
+// same and a wave that gives up raises kFlagRingTimeout (the host turns it into an error).
+//
+// C360 step: 27.4 ms against 31.1 (-12 %); depth 14: -3 %; depth 10: +8 % - the host picks these kernels for forests
+// of >= 7 steps per tree, as it does the tree tops (capi.cpp pick_kernel).
+constexpr int kRingChains = 4;
+constexpr int kRingWaves = 16;
+constexpr int kRingBlock = kRingWaves * kWave;
+constexpr uint32_t kRingSteps = 4;
+constexpr uint32_t kRingSlots = 176;                                   // records of a tree's first four steps
+constexpr uint32_t kRingBuffers = 4;
+constexpr uint32_t kRingTreeBytes = kRingSlots * 16u;
+constexpr uint32_t kRingBufBytes = kRingChains * kRingTreeBytes;        // 11 264
+constexpr uint32_t kRingDmaLoads = kRingChains * kRingSlots / kWave;    // 11 wave instructions per group
+static_assert(kRingChains * kRingSlots % kWave == 0, "a group is whole wave loads");
+constexpr uint32_t kRingSpinLimit = 1u << 21;
+constexpr size_t kRingLdsBytes = (size_t)kRingWaves * 27 * kWave * sizeof(float) + (size_t)kRingBuffers * kRingBufBytes +
+                                 (size_t)(kRingWaves + 4) * sizeof(uint32_t);
+static_assert(kRingLdsBytes <= 160 * 1024, "LDS of a block");
+
+__device__ __forceinline__ uint32_t ring_load(lds_u32_ptr p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void ring_store(lds_u32_ptr p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// LDS serves a wave's requests in order; this keeps the compiler from moving LDS accesses across and drains the
+// wave's outstanding LDS operations (not its vector-memory ones: a fence would wait for the rows in flight too)
+__device__ __forceinline__ void ring_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One wave instruction of LDS-DMA: 64 x 16 bytes from the buffer `desc` describes, at byte `off` per lane
+// (range-checked), to LDS at lds_addr + 16 * lane.  In assembly because hipcc puts `s_waitcnt vmcnt(0)` in front of
+// every LDS read that follows a DMA it knows of; the caller waits (vmcnt) before anybody reads what it wrote.
+__device__ __forceinline__ void dma_to_lds_b128(u32x4 desc, uint32_t off, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(off), "s"(desc), "s"(lds_addr)
+      : "memory");
+}
+
+// What a wave knows of its block's ring.
+struct TopRing {
+  lds_cptr ring;              // [kRingBuffers][kRingChains][kRingSlots] records
+  uint32_t ring_addr;         // the same as an LDS byte address (for the DMA's M0)
+  lds_u32_ptr progress, filled, claim;
+  u32x4 desc;                 // buffer descriptor over the forest's super-nodes
+  __amdgpu_buffer_rsrc_t forest;
+  const SuperTreeHead* heads;
+  uint32_t t0, t1, ngroups;   // trees of this launch, in groups of kRingChains
+  uint32_t total;             // groups every wave of the block goes through: rounds x ngroups
+  uint32_t g;                 // groups this wave is done with
+  bool gave_up;
+};
+
+// group `first_tree` .. + kRingChains - 1 (clamped to the last tree: a duplicate walk is discarded) -> buffer `buf`
+__device__ __forceinline__ void ring_stage(const TopRing& rg, uint32_t first_tree, uint32_t buf, int lane) {
+  uint32_t base[kRingChains];
+#pragma unroll
+  for (int c = 0; c < kRingChains; ++c) base[c] = rg.heads[(first_tree + c < rg.t1) ? first_tree + c : rg.t1 - 1].base;
+#pragma unroll
+  for (uint32_t q = 0; q < kRingDmaLoads; ++q) {
+    const uint32_t L = q * kWave + (uint32_t)lane;     // record L of the group: tree L / 176, record L % 176
+    uint32_t b = base[0], rec = L;
+#pragma unroll
+    for (int k = 1; k < kRingChains; ++k)
+      if (L >= (uint32_t)k * kRingSlots) b = base[k], rec = L - (uint32_t)k * kRingSlots;
+    dma_to_lds_b128(rg.desc, (b + rec) << 4, rg.ring_addr + buf * kRingBufBytes + q * 1024u);   // past the forest: zeros
+  }
+}
+
+// Every thread of the block: sets the ring up behind the block's tiles, stages group 0, one barrier.
+__device__ __forceinline__ void ring_begin(TopRing& rg, char* ring, const DeviceForest& fr, const SuperTreeHead* heads,
+                                           uint32_t t0, uint32_t t1, uint32_t rounds) {
+  const int lane = threadIdx.x & (kWave - 1);
+  rg.ring = (lds_cptr)ring;
+  rg.ring_addr = (uint32_t)(uintptr_t)(lds_void_ptr)ring;
+  rg.progress = (lds_u32_ptr)(ring + (size_t)kRingBuffers * kRingBufBytes);
+  rg.filled = rg.progress + kRingWaves;
+  rg.claim = rg.progress + kRingWaves + 1;
+  const uint64_t addr = reinterpret_cast<uint64_t>(fr.super);
+  rg.desc.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);
+  rg.desc.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(addr >> 32) & 0xFFFFu));
+  rg.desc.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)fr.super_bytes);
+  rg.desc.w = 0x00020000u;
+  rg.forest = make_rsrc(fr.super, fr.super_bytes);
+  rg.heads = heads;
+  rg.t0 = t0;
+  rg.t1 = t1;
+  rg.ngroups = (t1 - t0 + kRingChains - 1) / kRingChains;
+  rg.total = rounds * rg.ngroups;
+  rg.g = 0;
+  rg.gave_up = false;
+  if (threadIdx.x < kWave) {            // wave 0
+    ring_stage(rg, t0, 0u, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (threadIdx.x < (uint32_t)kRingWaves) ring_store(rg.progress + threadIdx.x, 0u);
+  if (threadIdx.x == 0) {
+    ring_store(rg.filled, 1u);
+    ring_store(rg.claim, 1u);
+  }
+  __syncthreads();
+}
+
+// one group of kRingChains trees for the wave's tile: steps 1 .. 4 from `tops` (LDS), the rest gathered.
+// publish_to: this wave staged the next group before this walk; it says so from in here (see below).
+template <bool HAS_MISSING>
+__device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingChains], uint32_t ntrees_here,
+                                                 __amdgpu_buffer_rsrc_t forest, const float* __restrict__ tile,
+                                                 lds_cptr tops, float acc, lds_u32_ptr publish_to,
+                                                 uint32_t publish_value) {
+  constexpr int CHAINS = kRingChains;
+  const char* tile_b = reinterpret_cast<const char*>(tile);
+  u32x4 s[CHAINS];
+  uint32_t rel[CHAINS], leafb[CHAINS];
+  float xr[CHAINS];
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) xr[c] = tile[(h[c].root_meta & 31u) * kWave];
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) {
+    bool l = xr[c] < h[c].root_thr;
+    if (HAS_MISSING) l = go_left_or_default(xr[c], h[c].root_thr, (h[c].root_meta & 32u) != 0u);
+    rel[c] = 4u + (((h[c].root_meta & 0x100u) && !l) ? 1u : 0u);
+    leafb[c] = 0u;
+  }
+  uint32_t nsteps = h[0].steps;
+#pragma unroll
+  for (int c = 1; c < CHAINS; ++c) nsteps = h[c].steps > nsteps ? h[c].steps : nsteps;
+  nsteps = nsteps < kRingSteps ? kRingSteps : nsteps;      // a shallow tree walks on through its fillers
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) s[c] = *(lds_u32x4_ptr)(tops + (uint32_t)c * kRingTreeBytes + (rel[c] << 4));
+#pragma unroll
+  for (uint32_t step = 1; step < kRingSteps; ++step) {
+    super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) s[c] = *(lds_u32x4_ptr)(tops + (uint32_t)c * kRingTreeBytes + (rel[c] << 4));
+  }
+  // the stager: its DMA of the next group was issued before this walk and has had the LDS steps' time to land;
+  // nothing else of this wave is in flight here but its next rows
+  if (publish_to != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & (kWave - 1)) == 0) ring_store(publish_to, publish_value);
+  }
+  for (uint32_t step = kRingSteps; step < nsteps; ++step) {
+    super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+      s[c] = __builtin_amdgcn_raw_buffer_load_b128(forest, (int)((h[c].base + rel[c]) << 4), 0, 0);
+  }
+  super_step<CHAINS, HAS_MISSING, true>(s, rel, leafb, tile_b);
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c)
+    if ((uint32_t)c < ntrees_here) acc += __uint_as_float(leafb[c]);
+  return acc;
+}
+
+// All trees of the launch for the wave's tile (live: the wave has one; a wave without still goes round: the others
+// count on its progress).  `last_round`: nothing is staged behind the last group of the block's last round.
+__device__ __forceinline__ float ring_walk_tile(TopRing& rg, float acc, const float* __restrict__ tile, bool live,
+                                                bool wave_nan, int lane, int wave) {
+  for (uint32_t p = 0; p < rg.ngroups; ++p, ++rg.g) {
+    const uint32_t g = rg.g;
+    const uint32_t t = rg.t0 + p * kRingChains;
+    // ---- first at group g?  then group g + 1 is this wave's to stage
+    uint32_t won = 0;
+    if (g + 1u < rg.total && !rg.gave_up) {
+      if (lane == 0) {
+        uint32_t expected = g + 1u;
+        won = __hip_atomic_compare_exchange_strong(rg.claim, &expected, g + 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+      }
+      won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
+    }
+    if (won) {
+      // its buffer held group g + 1 - kRingBuffers: every wave must be done with that one
+      const uint32_t need = g + 2u > kRingBuffers ? g + 2u - kRingBuffers : 0u;
+      uint32_t spin = 0;
+      while (!__all(lane >= kRingWaves || ring_load(rg.progress + (lane < kRingWaves ? lane : 0)) >= need)) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spin > kRingSpinLimit) { rg.gave_up = true; break; }
+      }
+      ring_order();
+      ring_stage(rg, (p + 1 == rg.ngroups) ? rg.t0 : t + kRingChains, (g + 1u) % kRingBuffers, lane);
+    }
+    // ---- group g complete in the ring?
+    {
+      uint32_t spin = 0;
+      while (ring_load(rg.filled) < g + 1u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spin > kRingSpinLimit) { rg.gave_up = true; break; }
+      }
+      ring_order();
+    }
+    // group g was complete before this wave walks it, so nobody else publishes meanwhile: g + 1 is next
+    const lds_u32_ptr pub = won ? rg.filled : (lds_u32_ptr) nullptr;
+    if (live && !rg.gave_up) {
+      SuperTreeHead h[kRingChains];
+#pragma unroll
+      for (int c = 0; c < kRingChains; ++c) h[c] = rg.heads[(t + c < rg.t1) ? t + c : rg.t1 - 1];
+      const uint32_t here = rg.t1 - t < (uint32_t)kRingChains ? rg.t1 - t : (uint32_t)kRingChains;
+      const lds_cptr buf = rg.ring + (g % kRingBuffers) * kRingBufBytes;
+      acc = wave_nan ? ring_walk_group<true>(h, here, rg.forest, tile, buf, acc, pub, g + 2u)
+                     : ring_walk_group<false>(h, here, rg.forest, tile, buf, acc, pub, g + 2u);
+    } else if (won) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // a stager without a tile
+      if (lane == 0) ring_store(rg.filled, g + 2u);
+    }
+    ring_order();                                             // the walk's reads of the buffer are done
+    if (lane == 0) ring_store(rg.progress + wave, g + 1u);
+  }
+  return acc;
+}
+
+// AoS rows (27 columns, 27 features) in, margins out: predict_rows_tile_kernel<2, .., true, ..>'s row handling (rows
+// fetched by the wave together, the next tile's in flight during the walk, rows with missing values left to the
+// second launch) around the ring walk.  Every wave of a block goes round as often as the block's first wave.
+__global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4))) void predict_rows_ring_kernel(
+    DeviceForest fr, PredictArgs a, const SuperTreeHead* __restrict__ heads, float* __restrict__ out) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  float* tile = lds + (size_t)wave * 27 * kWave + lane;
+  float* tile_base = tile - lane;
+  const bool missing_is_nan = a.missing != a.missing;
+  uint32_t block = blockIdx.x;
+  if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint64_t wave_id = (uint64_t)block * kRingWaves + wave;
+  const uint64_t nwaves = (uint64_t)gridDim.x * kRingWaves;
+  const uint64_t first_tile = a.tile_begin + (uint64_t)block * kRingWaves;
+  if (first_tile >= a.tile_end) return;
+  const uint32_t rounds = (uint32_t)((a.tile_end - first_tile + nwaves - 1) / nwaves);
+  TopRing rg;
+  ring_begin(rg, reinterpret_cast<char*>(lds + (size_t)kRingWaves * 27 * kWave), fr, heads, a.tree_begin, a.tree_end, rounds);
+  uint64_t tile_id = a.tile_begin + wave_id;
+  Row27 regs;
+  bool valid = false, together = false;
+  uint64_t row = 0;
+  if (tile_id < a.tile_end) {
+    row = launch_row(a, tile_id, lane, &valid);
+    together = a.run_log >= 2u && !__any(valid && (row == 0 || row + 1 == a.nrow));
+    if (together) load_pieces(regs, a, row, lane);
+    else load_row27(regs, a.rows, valid ? row : 0);
+  }
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const bool live = tile_id < a.tile_end && __any(valid);
+    const bool lane_nan = !live ? false
+                          : together ? store_pieces(tile_base, regs, a, __ballot(valid), lane, missing_is_nan)
+                                     : store_row27(tile, regs, valid, a.missing, missing_is_nan, a.flags);
+    const uint64_t next = tile_id + nwaves;
+    const uint64_t this_row = row;
+    const bool this_valid = valid;
+    if (next < a.tile_end) {
+      row = launch_row(a, next, lane, &valid);
+      together = a.run_log >= 2u && !__any(valid && (row == 0 || row + 1 == a.nrow));
+      if (together) load_pieces(regs, a, row, lane);   // in flight during the walk
+      else load_row27(regs, a.rows, valid ? row : 0);
+    } else {
+      valid = false;
+    }
+    bool wave_nan = __any(lane_nan);
+    bool keep = this_valid;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // rows with missing values leave for the second launch, as in predict_rows_tile_kernel
+    if (wave_nan && a.defer_count != nullptr && a.defer_cap == 0u) {
+      if ((tile_id & 7u) == 0u) {
+        const uint32_t n = 8u * (uint32_t)__popcll(__ballot(lane_nan));
+        if (lane == 0) atomicAdd(a.defer_count, n);
+      }
+    } else if (wave_nan && a.defer_count != nullptr) {
+      bool mine = false;
+#pragma unroll
+      for (int f = 0; f < 27; ++f) {
+        const float x = tile[f * kWave];
+        mine |= (x != x);
+      }
+      const bool leaves = mine && this_valid;
+      const uint64_t who = __ballot(leaves);
+      const uint32_t n = (uint32_t)__popcll(who);
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(a.defer_count, n);
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+      if (at + n <= a.defer_cap) {
+        if (leaves) a.defer_list[at + (uint32_t)__popcll(who & ((1ull << lane) - 1ull))] = (uint32_t)this_row;
+        keep = this_valid && !mine;
+        wave_nan = false;
+      }
+    }
+    const float acc = ring_walk_tile(rg, fr.base_score, tile, live, wave_nan, lane, wave);
+    if (live && keep && !rg.gave_up) __builtin_nontemporal_store(acc, out + this_row);
+    tile_id = next;
+  }
+  if (rg.gave_up && a.flags) atomicOr(a.flags, kFlagRingTimeout);
+}
+
+// The fused path (predict_fields_kernel's fill and store) around the ring walk.
+__global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4))) void predict_fields_ring_kernel(
+    DeviceForest fr, FieldsArgs a, const SuperTreeHead* __restrict__ heads, float* __restrict__ out,
+    float* __restrict__ margin_out) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  float* tile = lds + (size_t)wave * 27 * kWave + lane;
+  const bool missing_is_nan = a.missing != a.missing;
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t nrow = plane * (uint64_t)(a.k2 - a.k1 + 1);
+  const uint64_t slab = plane * (uint64_t)(a.k1 - a.src_k0);
+  const uint64_t slab_out = plane * (uint64_t)(a.k1 - a.out_k0);
+  uint32_t block = blockIdx.x;
+  if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint64_t wave_id = (uint64_t)block * kRingWaves + wave;
+  const uint64_t nwaves = (uint64_t)gridDim.x * kRingWaves;
+  const uint64_t first_tile = a.tile_begin + (uint64_t)block * kRingWaves;
+  if (first_tile >= a.tile_end) return;
+  const uint32_t rounds = (uint32_t)((a.tile_end - first_tile + nwaves - 1) / nwaves);
+  const float qnan = __builtin_nanf("");
+  TopRing rg;
+  ring_begin(rg, reinterpret_cast<char*>(lds + (size_t)kRingWaves * 27 * kWave), fr, heads, a.tree_begin, a.tree_end, rounds);
+  uint64_t tile_id = a.tile_begin + wave_id;
+  for (uint32_t r = 0; r < rounds; ++r, tile_id += nwaves) {
+    bool valid = false;
+    uint64_t m = 0;
+    if (tile_id < a.tile_end) m = tile_row(a.shape, tile_id, lane, nrow, &valid);
+    const bool live = __any(valid);
+    bool lane_nan = false, any_inf = false;
+    if (live) {
+      const uint64_t col = valid ? m % plane : 0;
+      // one field after the other, as in predict_fields_kernel (a burst of 27 loads measured slower)
+      for (uint32_t f = 0; f < 27u; ++f) {
+        float x = qnan;
+        if (valid && f < a.nfield) {
+          const float* src = a.field[f];
+          x = ((a.is2d_mask >> f) & 1u) ? src[col] : __builtin_nontemporal_load(src + slab + m);
+          if (f == a.pl_feature) x = x / 100.0f;
+          any_inf |= is_inf(x);
+          if (!missing_is_nan && x == a.missing) x = qnan;
+        }
+        if (!valid) x = 0.0f;
+        lane_nan |= (x != x);
+        tile[f * kWave] = x;
+      }
+      if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
+    }
+    bool wave_nan = __any(lane_nan);
+    bool keep = valid;
+    if (wave_nan && a.defer_count != nullptr && a.defer_cap == 0u) {
+      if ((tile_id & 7u) == 0u) {
+        const uint32_t n = 8u * (uint32_t)__popcll(__ballot(lane_nan && valid));
+        if (lane == 0) atomicAdd(a.defer_count, n);
+      }
+    } else if (wave_nan && a.defer_count != nullptr) {
+      const bool leaves = lane_nan && valid;
+      const uint64_t who = __ballot(leaves);
+      const uint32_t n = (uint32_t)__popcll(who);
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(a.defer_count, n);
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+      if (at + n <= a.defer_cap) {
+        if (leaves) a.defer_list[at + (uint32_t)__popcll(who & ((1ull << lane) - 1ull))] = (uint32_t)m;
+        keep = valid && !lane_nan;
+        wave_nan = false;
+      }
+    }
+    const float acc = ring_walk_tile(rg, fr.base_score, tile, live, wave_nan, lane, wave);
+    if (keep && !rg.gave_up) {
+      if (margin_out) margin_out[m] = acc;
+      float oh = acc;
+      if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);      // rounded once from double, as predict_fields_kernel
+      oh = oh * a.scale;
+      out[slab_out + m] = oh;
+    }
+  }
+  if (rg.gave_up && a.flags) atomicOr(a.flags, kFlagRingTimeout);
+}
+
 // The second launch of a small batch (PredictArgs::leaf_buf): one wave per tile, margin = ((base + leaf_0) + leaf_1) + ...
 __global__ __launch_bounds__(kBlock) void combine_leaves_kernel(PredictArgs a, float base_score, float* __restrict__ out) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -1326,6 +1728,38 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
   return hipGetLastError();
 }
 
+// The train of launches of predict_rows_ring_kernel: one 1 024-thread block per CU, `ring_rounds` tiles per wave
+// and launch (the waves of a block walk the same trees by construction; what a launch boundary still buys is that the
+// blocks of an XCD start on tree 0 together).
+hipError_t launch_rows_ring(const DeviceForest& fr, PredictArgs a, int num_cus, hipStream_t stream, const LaunchTuning& tune) {
+  hipError_t e = ensure_lds(predict_rows_ring_kernel, kRingLdsBytes);
+  if (e != hipSuccess) return e;
+  shape_rows(a, tune);
+  const uint64_t ntiles = a.shape.ntiles(a.nrow);
+  uint64_t grid = (ntiles + kRingWaves - 1) / kRingWaves;
+  if (grid > (uint64_t)num_cus) grid = (uint64_t)num_cus;
+  a.xcd_remap = tune.xcd_remap;
+  a.run_log = 0;
+  a.run_lo_bits = 0;
+  if (tune.coop_rows && a.perm == nullptr && a.ncol == 27) {
+    if (a.shape.im == 0) {
+      a.run_log = 6;
+    } else if (a.shape.li >= 2) {
+      a.run_log = a.shape.li;
+      a.run_lo_bits = a.shape.k_fastest ? a.shape.lk : 0u;
+    }
+  }
+  const uint64_t per_launch = tune.ring_rounds <= 0 ? ntiles : grid * kRingWaves * (uint64_t)tune.ring_rounds;
+  for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
+    a.tile_begin = t0;
+    a.tile_end = t0 + per_launch < ntiles ? t0 + per_launch : ntiles;
+    const uint64_t blocks = (a.tile_end - a.tile_begin + kRingWaves - 1) / kRingWaves;
+    hipLaunchKernelGGL(predict_rows_ring_kernel, dim3((unsigned)(blocks < grid ? blocks : grid)), dim3(kRingBlock),
+                       kRingLdsBytes, stream, fr, a, fr.super_heads, a.out);
+  }
+  return hipGetLastError();
+}
+
 // The second launch of a deferred-rows predict: the rows of the list, 64 per wave, each lane its own row, missing-aware.
 template <class K>
 hipError_t launch_deferred(K kernel, size_t lds, const DeviceForest& fr, PredictArgs a, int num_cus, hipStream_t stream) {
@@ -1359,6 +1793,7 @@ const char* kernel_kind_name(KernelKind k) {
     case KernelKind::Super2: return "super2";
     case KernelKind::Super3: return "super3";
     case KernelKind::Super4: return "super4";
+    case KernelKind::Ring: return "ring";
   }
   return "?";
 }
@@ -1368,7 +1803,7 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
   if (a_in.nrow == 0) return hipSuccess;
   PredictArgs a = a_in;
   const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
-                        kind == KernelKind::Super4;
+                        kind == KernelKind::Super4 || kind == KernelKind::Ring;
   const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
   const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && a.ncol <= fr.num_feature;
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
@@ -1428,6 +1863,15 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
 #define OHX_ROWS(FMT, CH)                    \
   if (fr.tree_tops) OHX_ROWS_T(FMT, CH, true); \
   OHX_ROWS_T(FMT, CH, false)
+  // the ring kernel takes the OH shape with the next rows in flight (a big batch); everything else of a booster
+  // that asked for it - small batches with their trees split over waves, other column counts, the second launch of
+  // the deferred rows - goes the super2 way
+  if (kind == KernelKind::Ring && pf && !split) {
+    hipError_t e_ = launch_rows_ring(fr, a, num_cus, stream, tune);
+    if (e_ == hipSuccess && listing)
+      e_ = launch_deferred(predict_rows_tile_kernel<2, 2, false, true>, lds, fr, a, num_cus, stream);
+    return e_;
+  }
   switch (kind) {
     case KernelKind::Packed1: OHX_ROWS_T(1, 1, false);
     case KernelKind::Packed2: OHX_ROWS_T(1, 2, false);
@@ -1443,11 +1887,12 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
 
 std::string predict_kernel_symbol(KernelKind kind, const DeviceForest& fr, uint32_t ncol, const LaunchTuning& tune) {
   const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
-                        kind == KernelKind::Super4;
+                        kind == KernelKind::Super4 || kind == KernelKind::Ring;
   const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
   const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && ncol <= fr.num_feature;
   if (kind == KernelKind::Wide || !tile_ok || (!is_super && fr.packed == nullptr)) return "predict_rows_direct_kernel<false>";
   const bool pf = ncol == 27 && fr.num_feature == 27 && tune.launches_per_residency != 1 && tune.prefetch;
+  if (kind == KernelKind::Ring && pf) return "predict_rows_ring_kernel";
   int chains = 2;
   if (kind == KernelKind::Packed1 || kind == KernelKind::Super1) chains = 1;
   if (kind == KernelKind::Super3) chains = 3;
@@ -1460,7 +1905,11 @@ std::string predict_kernel_symbol(KernelKind kind, const DeviceForest& fr, uint3
 // keeps the waves of an XCD on the same few trees.
 template <class K>
 hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, FieldsArgs a, uint64_t nrow, int num_cus,
-                               hipStream_t stream, const LaunchTuning& tune) {
+                               hipStream_t stream, const LaunchTuning& tune, int waves_per_block = kWavesPerBlock,
+                               int rounds = -1) {
+  if (rounds < 0) rounds = tune.launches_per_residency;
+  const bool ring = waves_per_block != kWavesPerBlock;
+  const unsigned threads = (unsigned)waves_per_block * kWave;
   hipError_t e = ensure_lds(kernel, lds);
   if (e != hipSuccess) return e;
   if (tune.brick_li < 0) a.shape.set_grid_auto((uint32_t)a.im, (uint32_t)a.jm, 0, nrow);
@@ -1471,7 +1920,11 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
   a.xcd_remap = tune.xcd_remap;
   if (a.shape.ntiles(nrow) >= 0xFFFFFFFFull) a.shape = TileShape();
   const uint64_t ntiles = a.shape.ntiles(nrow);
-  const int grid = tile_grid(kernel, lds, ntiles, num_cus);
+  int grid = tile_grid(kernel, lds, ntiles, num_cus);
+  if (ring) {        // one block per CU
+    const uint64_t blocks = (ntiles + waves_per_block - 1) / waves_per_block;
+    grid = (int)(blocks < (uint64_t)num_cus ? blocks : (uint64_t)num_cus);
+  }
   // rows with missing values are left to a second launch (PredictArgs::defer_list)
   constexpr uint64_t kDeferMinRows = 1u << 18;
   if (tune.defer_buf != nullptr && tune.defer_words >= 2 && nrow < 0xFFFFFFF0ull && fr.num_feature == 27 &&
@@ -1484,18 +1937,16 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
     if (e == hipSuccess && a.defer_cap) e = hipMemsetAsync(a.defer_list, 0xFF, (size_t)a.defer_cap * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
   }
-  const uint64_t per_launch = tune.launches_per_residency <= 0
-                                  ? ntiles
-                                  : (uint64_t)grid * kWavesPerBlock * (uint64_t)tune.launches_per_residency;
+  const uint64_t per_launch = rounds <= 0 ? ntiles : (uint64_t)grid * waves_per_block * (uint64_t)rounds;
   TrainCursor train(stream, tune);
   for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
     a.tile_begin = t0;
     a.tile_end = t0 + per_launch < ntiles ? t0 + per_launch : ntiles;
-    const uint64_t blocks = (a.tile_end - a.tile_begin + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint64_t blocks = (a.tile_end - a.tile_begin + waves_per_block - 1) / waves_per_block;
     hipStream_t s;
     e = train.next(&s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < (uint64_t)grid ? blocks : (uint64_t)grid)), dim3(kBlock), lds,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks < (uint64_t)grid ? blocks : (uint64_t)grid)), dim3(threads), lds,
                        s, fr, a, fr.super_heads, a.out, a.margin_out);
   }
   e = train.meet();
@@ -1509,8 +1960,17 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
     a.defer_count = nullptr;
     a.tile_begin = 0;
     a.tile_end = ((uint64_t)a.defer_cap + kWave - 1) / kWave;
-    const int grid2 = tile_grid(kernel, lds, a.tile_end, num_cus);
-    hipLaunchKernelGGL(kernel, dim3(grid2), dim3(kBlock), lds, stream, fr, a, fr.super_heads, a.out, a.margin_out);
+    if (ring) {      // the listed rows go through the tile kernel (a lane per row, missing-aware)
+      auto second = predict_fields_kernel<2, 2, true>;
+      const size_t lds2 = tile_lds_bytes(fr.num_feature, true);
+      e = ensure_lds(second, lds2);
+      if (e != hipSuccess) return e;
+      const int grid2 = tile_grid(second, lds2, a.tile_end, num_cus);
+      hipLaunchKernelGGL(second, dim3(grid2), dim3(kBlock), lds2, stream, fr, a, fr.super_heads, a.out, a.margin_out);
+    } else {
+      const int grid2 = tile_grid(kernel, lds, a.tile_end, num_cus);
+      hipLaunchKernelGGL(kernel, dim3(grid2), dim3(kBlock), lds, stream, fr, a, fr.super_heads, a.out, a.margin_out);
+    }
   }
   return hipGetLastError();
 }
@@ -1520,7 +1980,7 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   if (a.k2 < a.k1 || a.im <= 0 || a.jm <= 0) return hipSuccess;
   const uint64_t nrow = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)(a.k2 - a.k1 + 1);
   const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
-                        kind == KernelKind::Super4;
+                        kind == KernelKind::Super4 || kind == KernelKind::Ring;
   const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
   if (fr.num_feature < 1 || lds > 160 * 1024) return hipErrorInvalidValue;
   if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
@@ -1532,6 +1992,11 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   if (fr.tree_tops) OHX_LAUNCH_FIELDS_T(FMT, CH, true); \
   OHX_LAUNCH_FIELDS_T(FMT, CH, false)
   if (use_wide) OHX_LAUNCH_FIELDS_T(0, 1, false);
+  // the ring kernel for slabs that fill the chip at least twice; smaller ones (a rank-sized block) the super2 way:
+  // a block of the ring kernel is 16 tiles that wait for each other's trees
+  if (kind == KernelKind::Ring && fr.num_feature == 27 && nrow >= (uint64_t)num_cus * kRingWaves * kWave * 2u)
+    return launch_fields_tiled(predict_fields_ring_kernel, kRingLdsBytes, fr, a, nrow, num_cus, stream, tune, kRingWaves,
+                               tune.ring_rounds);
   switch (kind) {
     case KernelKind::Packed1: OHX_LAUNCH_FIELDS_T(1, 1, false);
     case KernelKind::Packed2: OHX_LAUNCH_FIELDS_T(1, 2, false);

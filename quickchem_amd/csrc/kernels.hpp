@@ -12,6 +12,7 @@ namespace ohx {
 // Flag bits the kernels raise in a device word
 enum : uint32_t {
   kFlagInfInput = 1u,  // an input value was +-inf while `missing` is finite
+  kFlagRingTimeout = 2u,  // ring kernels: a wave gave up waiting for another (the results are invalid)
 };
 
 // trees whose first-step super-nodes the tile kernels keep in LDS (kernels.hip)
@@ -163,6 +164,8 @@ struct LaunchTuning {
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
   int coop_rows = 1;  // ... fetched by the wave together where a tile is made of runs of >= 4 consecutive rows
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
+  // ring kernels: tiles per wave and launch (0 = one launch for the whole batch)
+  int ring_rounds = 8;
   // small batches: trees split over several waves per tile (PredictArgs::leaf_buf): -1 = when the batch leaves half of
   // the chip's wave slots empty, 0 = never, n > 1 = always in n runs; needs the booster's leaf buffer
   int tree_split = -1;
@@ -278,7 +281,9 @@ hipError_t launch_cluster_keys(const DeviceForest& forest, const ClusterArgs& a,
 hipError_t sort_pairs_u32(void* temp, size_t* temp_bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
                           uint32_t* vals_b, uint64_t n, unsigned key_bits, hipStream_t stream, uint32_t** sorted_vals);
 
-enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super3, Super4 };
+// Ring: super-nodes, the records of a walk's first four steps resident in LDS (predict_rows_ring_kernel /
+// predict_fields_ring_kernel); falls back to Super2 for what those kernels do not take (small batches, other shapes)
+enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super3, Super4, Ring };
 
 const char* kernel_kind_name(KernelKind k);
 // the __global__ launch_predict would launch for rows of `ncol` columns (for profiles and bench.py)

@@ -2,7 +2,7 @@
 !  module name, procedure names and keyword arguments.
 !
 !  ESMF cannot be built here (SURVEY.md §8c), and GEOS itself is out of tree.  The OH GridComp shell
-!  (../oh_gridcomp.F90, ../quickchem_gridcomp.F90) says `use ESMF` / `use MAPL` and calls ESMF_ConfigGetAttribute,
+!  (../oh_gridcomp.F90; and the reference's own QuickChem_GridCompMod.F90, compiled in place by oracle/Makefile) says `use ESMF` / `use MAPL` and calls ESMF_ConfigGetAttribute,
 !  ESMF_GridCompGet, ESMF_UserCompSetInternalState, ESMF_ClockGet, ESMF_AlarmIsRinging ... exactly as the
 !  reference does (OH_GridComp/OH_GridCompMod.F90:516-605, 793, 855-897, 1147-1185, 1820): inside GEOS the same
 !  two source files compile against the real libraries, here against this directory (mapl_lite/), which a GEOS

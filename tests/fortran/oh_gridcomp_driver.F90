@@ -1,14 +1,16 @@
 !  oh_gridcomp_driver -- a mock GEOS cap around QuickChem: BASELINE.json config #1, "a synthetic MAPL state
 !  through OH_GridComp Run".  SetServices of the parent (which creates the OH instances), Initialize, then
 !  `nticks` heartbeats of Run phase 1, Run phase 2 and clock advance, through the ESMF / MAPL calls a cap makes, served by
-!  the mock in mapl_lite/ (no MAPL, no ESMF here).  Being the mock's cap it also plays "the rest of GEOS": storage for
+!  the mock in quickchem_amd/fortran/mapl_lite/ (no MAPL, no ESMF here).  The parent, QuickChem_GridCompMod, is the
+!  reference's own unmodified file, compiled in place by oracle/Makefile (target `ref`); the child is the product's.  Being the mock's cap it also plays "the rest of GEOS": storage for
 !  the imports, HISTORY's wish list of exports, the model moving between heartbeats (esmfl_ / mapll_ calls).
 !
 !  usage: oh_gridcomp_driver <run dir> <state.bin> <out.bin> <nticks>
 !
 !  <run dir> holds the resource files the components read: AGCM.rc (RUN_DT, QUICKCHEM_DT, OH_DT,
 !  OH_REFERENCE_TIME, and for this driver BEG_DATE: yyyymmdd hhmmss, OH_EXPORTS: names HISTORY would ask for,
-!  AVG24_READY_TICK: the heartbeat before which the *_avg24 imports become valid, -1 = never),
+!  AVG24_READY_TICK: the heartbeat before which the *_avg24 imports become valid, -1 = never; SPEC_DUMP: a file that
+!  receives what every instance's SetServices registered),
 !  QuickChem_GridComp.rc, OH_instance_<name>.rc, GOCART2G_GridComp.rc.
 !
 !  state.bin (stream, little endian, written by tests/):
@@ -31,7 +33,7 @@ program oh_gridcomp_driver
    use OH_GridCompMod, only: oh_last_run
    implicit none
 
-   character(len=ESMF_MAXPATHLEN) :: rundir, state_file, out_file, arg, model_file
+   character(len=ESMF_MAXPATHLEN) :: rundir, state_file, out_file, arg, model_file, spec_file
    character(len=32) :: recname
    character(len=ESMF_MAXSTR) :: tok, child_name
    character(len=ESMF_MAXSTR), allocatable :: want(:)
@@ -46,7 +48,7 @@ program oh_gridcomp_driver
    type(ESMF_Time) :: start, now
    type(ESMF_TimeInterval) :: heartbeat
    integer(c_int32_t) :: im, jm, km, n4, nrec, kind
-   integer :: rc, u, uo, nticks, tick, i, c, q, beg_date, beg_time, dt, nymd, nhms, yy, mm, dd, h, m, s, nwant, trc
+   integer :: rc, u, uo, us, nticks, tick, i, c, q, beg_date, beg_time, dt, nymd, nhms, yy, mm, dd, h, m, s, nwant, trc
    integer :: avg24_tick, k1, k2, ninst
    logical :: ran, boosted, running
    real, pointer :: p2(:,:), p3(:,:,:), p4(:,:,:,:), oh(:,:,:), parent_oh(:,:,:)
@@ -95,13 +97,29 @@ program oh_gridcomp_driver
    clock = ESMF_ClockCreate(timeStep=heartbeat, startTime=start, rc=rc)
 
    root = ESMF_GridCompCreate(name='QUICKCHEM', config=agcm, grid=grid, rc=rc)
-   call ESMF_GridCompSetServices(root, QuickChem_SetServices, rc=rc)
+   call set_services_of(root, QuickChem_SetServices, rc)
    if (rc /= ESMF_SUCCESS) call die('QuickChem SetServices failed')
    call MAPL_GetObjectFromGC(root, meta, rc)
    call MAPL_Get(meta, gcs=gcs, gim=gim, gex=gex, rc=rc)
    call ESMF_GridCompGet(gcs(1), name=child_name)
    call IS_QC_INSTANCE_RUNNING('OH', trim(child_name), running, rc)
    if (rc /= ESMF_SUCCESS .or. .not. running) call die('IS_QC_INSTANCE_RUNNING does not know the first OH instance')
+
+   !  AGCM.rc `SPEC_DUMP: <file>`: what every instance's SetServices registered, one line per field -
+   !  instance|state|short name|dims|vlocation|restart|refresh|averaging|ungridded|add2export|units|long name
+   call ESMF_ConfigGetAttribute(agcm, spec_file, label='SPEC_DUMP:', default='', rc=rc)
+   if (len_trim(spec_file) > 0) then
+      open(newunit=us, file=trim(spec_file), status='replace', action='write')
+      do c = 1, size(gcs)
+         call ESMF_GridCompGet(gcs(c), name=child_name)
+         call MAPL_GetObjectFromGC(gcs(c), cmeta, rc)
+         call MAPL_Get(cmeta, INTERNAL_ESMF_STATE=internal, rc=rc)
+         call dump_state(us, trim(child_name), 'IMPORT', gim(c))
+         call dump_state(us, trim(child_name), 'EXPORT', gex(c))
+         call dump_state(us, trim(child_name), 'INTERNAL', internal)
+      end do
+      close(us)
+   end if
 
    !  the rest of GEOS: storage for every import, filled from the state file by name; HISTORY: the exports asked for
    do c = 1, size(gcs)
@@ -165,11 +183,12 @@ program oh_gridcomp_driver
       do c = 1, size(gcs)
          call MAPL_GetObjectFromGC(gcs(c), cmeta, rc)
          call MAPL_Get(cmeta, INTERNAL_ESMF_STATE=internal, rc=rc)
-         call MAPL_GetPointer(internal, oh, 'OH', rc=rc)
-         if (is_data(c)) then
-            write(uo) oh
+         if (is_data(c)) then                   ! INTERNAL OH of a data instance: (im,jm,km,nbins), nbins = 1
+            call MAPL_GetPointer(internal, p4, 'OH', rc=rc)
+            write(uo) p4(:,:,:,1)
             cycle
          end if
+         call MAPL_GetPointer(internal, oh, 'OH', rc=rc)
          call oh_last_run(gcs(c), ran, boosted, model_file, k1, k2)
          write(uo) merge(1_c_int32_t, 0_c_int32_t, ran), merge(1_c_int32_t, 0_c_int32_t, boosted), &
                    int(k1, c_int32_t), int(k2, c_int32_t)
@@ -192,6 +211,30 @@ program oh_gridcomp_driver
    close(uo)
 
 contains
+
+   !  The parent's SetServices is the reference's own routine, whose RC is OPTIONAL (QuickChem_GridCompMod.F90:78-83);
+   !  GEOS hands such routines on as `external` procedures (as the parent itself does with its children's, :516-531)
+   subroutine set_services_of(gc, ss, rc)
+      type(ESMF_GridComp), intent(inout) :: gc
+      external :: ss
+      integer, intent(out) :: rc
+      call ESMF_GridCompSetServices(gc, ss, rc=rc)
+   end subroutine
+
+   subroutine dump_state(unit, inst, which, state)
+      integer, intent(in) :: unit
+      character(len=*), intent(in) :: inst, which
+      type(ESMF_State), intent(in) :: state
+      integer :: n
+      if (.not. associated(state%p)) return
+      do n = 1, state%p%n
+         associate (f => state%p%f(n))
+            write(unit, '(a,"|",a,"|",a,"|",i0,"|",i0,"|",i0,"|",i0,"|",i0,"|",i0,"|",l1,"|",a,"|",a)') inst, which, &
+               trim(f%name), f%dims, f%vloc, f%restart, f%refresh_interval, f%averaging_interval, f%ungridded, &
+               f%add2export, trim(f%units), trim(f%long_name)
+         end associate
+      end do
+   end subroutine
 
    subroutine die(msg)
       character(len=*), intent(in) :: msg

@@ -14,7 +14,7 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["wide", "packed1", "packed2", "packed4", "super1", "super2", "super3", "super4"]
+KERNELS = ["wide", "packed1", "packed2", "packed4", "super1", "super2", "super3", "super4", "ring"]
 
 
 @pytest.fixture(scope="module")
@@ -630,6 +630,7 @@ def test_tree_tops_walk_gives_the_same_margins(torch_cuda, small_model, deep_mod
             got = gpu_predict(image, x, miss, kernel, params={"ohx_tree_tops": tops})
             assert np.array_equal(helpers.bits(got), helpers.bits(want)), (kernel, tops, deep)
         b = capi.Booster(model_buffer=image)
+        b.set_param("ohx_kernel", "super2")          # (`auto` takes a deep booster's big batches to the ring kernel)
         b.set_param("ohx_tree_tops", tops)
         sym = b.kernel_symbol(x.shape[1])
         uses = {"on": True, "off": False, "auto": deep}[tops]
@@ -721,3 +722,123 @@ def test_random_grids_shards_and_brick_shapes(torch_cuda):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.run(150, 20261004) == []
+
+
+# ------------------------------------------------------------------ the ring kernels (tree tops resident in LDS)
+
+RING = {"ohx_tree_split": "off"}          # a small batch would have its trees split over waves (the super2 way) instead
+
+
+def test_ring_kernel_is_the_default_for_deep_boosters(torch_cuda, small_model, deep_model):
+    """`auto` sends a deep booster's OH-shaped batches (27 columns, >= 7 steps per tree) through predict_rows_ring_kernel
+    and a shallow booster's through the tile kernel; the library names what it launches."""
+    for image, want in ((deep_model.image, "predict_rows_ring_kernel"), (small_model.image, "predict_rows_tile_kernel<2,2,true,false>")):
+        b = capi.Booster(model_buffer=image)
+        assert b.kernel_symbol(27) == want
+        b.free()
+    b = capi.Booster(model_buffer=small_model.image)
+    b.set_param("ohx_kernel", "ring")
+    assert b.kernel_symbol(27) == "predict_rows_ring_kernel"
+    assert b.kernel_symbol(20).startswith("predict_rows_tile_kernel<2,2,false")      # other shapes: the super2 way
+    b.free()
+
+
+@pytest.mark.parametrize("nrows", [1, 63, 65, 1000, 16 * 64 + 1, 62208, 96 * 72 * 9 + 5])
+def test_ring_rows_vs_oracle_ragged_sizes(torch_cuda, deep_model, small_model, nrows):
+    """Batches that do not fill a block's 16 tiles, a wave's 64 lanes or a launch's rounds: waves without a tile still go
+    round (the others count on their progress).  Deep booster (9 steps: four from LDS, five gathered) and the shallow one
+    (5 steps), consecutive rows and bricks, one round per launch and everything in one launch."""
+    grid = (96, 72, 72)
+    rows = synth.rows_cpu(grid, 777, nrows)
+    for image in (deep_model.image, small_model.image):
+        want = helpers.oracle_predict(image, rows, synth.XX_MISS)
+        for hint, extra in (((0, 0, 0), {}), ((96, 72, 777), {}), ((96, 72, 777), {"ohx_ring_rounds": 1}),
+                            ((96, 72, 777), {"ohx_ring_rounds": 0}), ((96, 72, 777), {"ohx_xcd_remap": 0})):
+            got = gpu_predict(image, rows, synth.XX_MISS, "ring", params=dict(RING, **extra), grid=hint)
+            assert np.array_equal(helpers.bits(got), helpers.bits(want)), (hint, extra)
+
+
+def test_ring_tree_counts_that_are_not_multiples_of_four(torch_cuda, deep_model):
+    """Groups of four trees: a tree limit that leaves one, two or three trees in the last group (the spare chains walk the
+    last tree again and their leaves are dropped), a single tree, a single group."""
+    rows = with_missing(synth.rows_cpu(synth.GRIDS["C12"], 0, 30000), 0.002)
+    for lim in (1, 2, 3, 4, 5, 37, 98, 99, 100):
+        want = helpers.oracle_predict(deep_model.image, rows, synth.XX_MISS, ntree_limit=lim)
+        got = gpu_predict(deep_model.image, rows, synth.XX_MISS, "ring", ntree_limit=lim, params=RING, grid=(12, 72, 0))
+        assert np.array_equal(helpers.bits(got), helpers.bits(want)), lim
+
+
+@pytest.mark.parametrize("missing", [synth.XX_MISS, float("nan")])
+def test_ring_missing_values_and_the_second_launch(torch_cuda, deep_model, missing):
+    """Missing values in the ring kernel: walked missing-aware by the wave that holds them (deferral off), or listed for
+    the second launch (on; at 5 % the list overflows and the later waves walk missing-aware)."""
+    grid = (96, 72, 72)
+    for rate in (1e-4, 3e-3, 0.05):
+        rows = with_missing(synth.rows_cpu(grid, 1234, 96 * 72 * 6 + 777), rate, seed=11)
+        if missing != missing:
+            rows[rows == np.float32(synth.XX_MISS)] = np.nan
+        want = helpers.oracle_predict(deep_model.image, rows, missing)
+        for defer in ("on", "off"):
+            for hint in ((96, 72, 1234), (0, 0, 0)):
+                got = gpu_predict(deep_model.image, rows, missing, "ring", params=dict(RING, ohx_defer_missing=defer), grid=hint)
+                assert np.array_equal(helpers.bits(got), helpers.bits(want)), (rate, defer, hint)
+
+
+def test_ring_golden_vectors_and_odd_boosters(torch_cuda):
+    """The hand-made forest (five trees, one to three steps: every walk ends among fillers long before the fourth LDS
+    step) and a booster of 150 shallow trees (more than the tile kernels' first-step table holds) through the ring kernel."""
+    import json as _json
+    doc = _json.load(open(os.path.join(helpers.GOLDEN, "hand_forest.json")))
+    doc["learner"]["learner_model_param"]["num_feature"] = "27"       # the ring kernels take 27-feature boosters only:
+    for t in doc["learner"]["gradient_booster"]["model"]["trees"]:     # the same trees, 24 features nobody splits on
+        t["tree_param"]["num_feature"] = "27"
+    hand = _json.dumps(doc).encode()
+    cases, x = helpers.load_hand_cases()
+    x27 = np.full((x.shape[0], 27), np.float32(cases["missing"]), dtype=np.float32)
+    x27[:, :x.shape[1]] = x
+    got = gpu_predict(hand, x27, cases["missing"], "ring", params=RING)
+    assert np.array_equal(helpers.bits(got), helpers.bits(np.float32(cases["margin"])))      # the hand-computed answers
+    many = synth.make_model(num_trees=150, max_depth=5, sample_log2=12, min_leaf=2, grid=synth.GRIDS["C12"])
+    rows = with_missing(synth.rows_cpu(synth.GRIDS["C12"], 0, 12 * 72 * 30), 0.01)
+    want = helpers.oracle_predict(many.image, rows, synth.XX_MISS)
+    got = gpu_predict(many.image, rows, synth.XX_MISS, "ring", params=RING)
+    assert np.array_equal(helpers.bits(got), helpers.bits(want))
+
+
+def test_ring_rows_in_no_order(torch_cuda, deep_model):
+    """Shuffled rows go through the clustering pass's permutation into the ring kernel (every lane its own row)."""
+    rng = np.random.default_rng(5)
+    rows = synth.rows_cpu((96, 72, 72), 0, 96 * 72 * 8)
+    rows = rows[rng.permutation(rows.shape[0])]
+    want = helpers.oracle_predict(deep_model.image, rows, synth.XX_MISS)
+    for cluster in ("on", "off"):
+        got = gpu_predict(deep_model.image, rows, synth.XX_MISS, "ring", params=dict(RING, ohx_cluster=cluster))
+        assert np.array_equal(helpers.bits(got), helpers.bits(want)), cluster
+
+
+@pytest.mark.parametrize("dynamic", [True, False])
+def test_ring_fused_fields_vs_oracle(torch_cuda, deep_model, dynamic):
+    """The fused call on a slab big enough for predict_fields_ring_kernel (>= two residencies of the chip), with -999.0 and
+    NaN in the fields, the rows that hold them listed for the second launch or walked in place; margins bit for bit."""
+    grid = (96, 72, 80)
+    pl, tropp, fields = helpers.synth_state(grid)
+    rng = np.random.default_rng(23)
+    fields = [f.copy() for f in fields]
+    for f in fields[2:]:
+        mask = rng.random(f.shape) < 2e-4
+        f[mask] = np.where(rng.random(int(mask.sum())) < 0.5, np.float32(synth.XX_MISS), np.float32(np.nan))
+    oh_ref, margin_ref, k1, k2 = helpers.oracle_predict_oh(deep_model.image, pl, tropp, fields, dynamic)
+    assert grid[0] * grid[1] * (k2 - k1 + 1) >= 256 * 16 * 64 * 2, (k1, k2)
+    for defer in ("on", "off"):
+        p = oh_predict.OHPredictor()
+        p.xx_bst = capi.Booster(model_buffer=deep_model.image)
+        p.xx_bst.set_param("ohx_kernel", "ring")
+        p.xx_bst.set_param("ohx_defer_missing", defer)
+        p.first_time = False
+        oh = np.zeros(grid, dtype=np.float32)
+        margins = []
+        assert p.predict_OH_with_XGB("unused", *grid, dynamic, 4000.0, pl, tropp, oh_predict.OHBoostInputData(fields), oh,
+                                     mode="fused", margin_out=margins) == 0
+        assert np.array_equal(helpers.bits(margins[0]), helpers.bits(margin_ref)), defer
+        assert np.all(oh[:, :, :k1 - 1] == 0)
+        assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2

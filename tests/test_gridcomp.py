@@ -1,7 +1,9 @@
 """SURVEY.md §8(f)-4 / BASELINE.json config #1 as worded: "a synthetic MAPL state through OH_GridComp Run".
 
-The OH GridComp shell (quickchem_amd/fortran/oh_gridcomp.F90 under quickchem_gridcomp.F90, on the mapl_lite mock)
-is driven over model days by a mock GEOS cap (oh_gridcomp_driver.F90).  Linked against the oracle it is the CPU
+The OH GridComp shell (quickchem_amd/fortran/oh_gridcomp.F90, on the mapl_lite mock) runs as the child of the
+REFERENCE'S OWN parent: QuickChem_GridCompMod.F90 and Shared/QuickChem_Generic.F90, unmodified, compiled in place from
+/root/reference into oracle/_ref/ by oracle/Makefile (target `ref`; skipped where neither the reference nor a prebuilt
+oracle/_ref is there) - driven over model days by a mock GEOS cap (tests/fortran/oh_gridcomp_driver.F90).  Linked against the oracle it is the CPU
 plumbing case; linked against libohxgb.so (-m gpu) the same shell runs its arithmetic on the MI355X.  What the
 shell decides - alarm gate, need_to_call_BOOST, which import feeds which input (OH_data_source, spin-up), the month
 in the model file name, what persists between ticks - is restated here tick by tick in Python, and the numbers come
@@ -19,8 +21,12 @@ import pytest
 from quickchem_amd import capi, synth
 from tests import helpers
 
-DRIVER_ORACLE = os.path.join(helpers.ROOT, "oracle", "lib", "oh_gridcomp_driver_oracle")
-DRIVER_HIP = os.path.join(helpers.ROOT, "quickchem_amd", "lib", "oh_gridcomp_driver_hip")
+DRIVER_ORACLE = os.path.join(helpers.ROOT, "oracle", "_ref", "oh_gridcomp_driver_oracle")
+DRIVER_HIP = os.path.join(helpers.ROOT, "oracle", "_ref", "oh_gridcomp_driver_hip")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(DRIVER_ORACLE),
+                                reason="oracle/_ref not built: the parent grid component is the reference's own file "
+                                       "(/root/reference/QuickChem_GridCompMod.F90), compiled in place by oracle/Makefile")
 
 F32 = np.float32
 EPSILON = float(F32(18.015) / F32(28.965))        # MAPL_H2OMW / MAPL_AIRMW in real32, as mapl_lite computes it
@@ -373,7 +379,7 @@ def test_setservices_refuses_what_the_reference_refuses(tmp_path, small_model):
 
 def test_passive_data_instance_and_a_start_after_midnight(tmp_path, small_model):
     """QuickChem_GridComp.rc lists: an active computational instance and a passive data-driven one
-    (its name contains 'data': Run_data copies oh_OH into INTERNAL OH, no phase 2).  The run starts at 06:00 with
+    (its name contains 'data': Run_data copies its import climoh001 into INTERNAL OH, no phase 2).  The run starts at 06:00 with
     compute_once_per_day: Boost is not due until midnight, and INTERNAL OH is built from the zero-filled OH_ML
     (the reference reads uninitialised memory here, :893,1582)."""
     grid = (3, 3, 16)
@@ -384,7 +390,8 @@ def test_passive_data_instance_and_a_start_after_midnight(tmp_path, small_model)
                  oh_dt=3600, ref_time="010000", beg="20240310 060000", exports=["OH_boost"], passive="OH.data")
     # the data instance reads OH_instance_OH.data.rc if there is one, else OH_instance_OH.rc (:533-538)
     state, out = tmp_path / "state.bin", tmp_path / "out.bin"
-    write_state_file(state, grid, imports, lats, lons)
+    clim = (np.random.default_rng(4).random(grid) * 1e-13).astype(F32)
+    write_state_file(state, grid, dict(imports, climoh001=clim), lats, lons)
     r = run_driver(DRIVER_ORACLE, rundir, state, out, 3)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "OH_instance_OH.data.rc does not exist" in r.stdout
@@ -392,7 +399,7 @@ def test_passive_data_instance_and_a_start_after_midnight(tmp_path, small_model)
     pl = (imports["PLE"][:, :, :-1] + imports["PLE"][:, :, 1:]) * F32(0.5)
     for t in got:
         assert t["OH"]["ran"] and not t["OH"]["boosted"]
-        assert np.array_equal(t["OH.data"]["OH"], imports["oh_OH"])
+        assert np.array_equal(t["OH.data"]["OH"], clim)
         assert np.all(t["OH"]["OH_boost"] == 0)
     below = pl > imports["TROPP"][:, :, None]                     # tick 0: the model has not moved yet
     assert below.any() and np.all(got[0]["OH"]["OH"][below] == 0)
@@ -423,3 +430,86 @@ def test_mapl_lite_config_reader(tmp_path):
     (rundir / "AGCM.rc").write_text(agcm.replace("BEG_DATE", "BEGIN"))
     r = run_driver(DRIVER_ORACLE, rundir, state, out, 1)
     assert r.returncode != 0 and "BEG_DATE" in r.stdout
+
+
+# ------------------------------------------------------------------ the spec table
+
+MAPL_CODE = {"MAPL_DimsHorzOnly": 2, "MAPL_DimsHorzVert": 3, "MAPL_VLocationNone": 0, "MAPL_VLocationCenter": 1,
+             "MAPL_VLocationEdge": 2, "MAPL_RestartOptional": 0, "MAPL_RestartSkip": 1, "MAPL_RestartRequired": 2}
+MAPL_CODE.update({k.lower(): v for k, v in list(MAPL_CODE.items())})
+
+
+def expected_specs(golden, source, spinup, nbins=1, n4=len(WAVELENGTHS)):
+    """What the reference's SetServices registers for a computational instance with this OH_data_source (None: a
+    data-driven instance), from tests/golden/oh_specs.json: {(state, short name): (dims, vloc, restart, refresh,
+    averaging, ungridded, add2export, units, long name)}."""
+    dflt = golden["mapl_defaults"]
+
+    def row(state, r, ungridded=0):
+        if "ungridded_dims" in r:
+            ungridded = {"[self%nbins]": nbins, "[self%n_wavelengths_profile]": n4}[r["ungridded_dims"]]
+        return ((state, r["short_name"]),
+                (MAPL_CODE[r["dims"].lower()], MAPL_CODE[r.get("vlocation", dflt["vlocation"]).lower()],
+                 MAPL_CODE[r.get("restart", dflt["restart"]).lower()], r.get("refresh_interval", 0),
+                 r.get("averaging_interval", 0), ungridded, bool(r.get("add2export", False)) and state == "INTERNAL",
+                 r.get("units", ""), r.get("long_name", "").rstrip()))
+    out = []
+    if source is None:
+        for r in golden["data_instance"]:
+            if "per" in r:
+                for b in range(1, nbins + 1):
+                    out.append(row(r["state"], dict(r, short_name=r["short_name"].format(bin=b),
+                                                    long_name=r["long_name"].format(bin=b))))
+            else:
+                out.append(row(r["state"], r))
+        return dict(out)
+    for state in ("IMPORT", "EXPORT", "INTERNAL"):
+        out += [row(state, r) for r in golden["state_specs"][state]]
+    blocks = ["always"]
+    if source == "ONLINE_INST" or (source == "ONLINE_AVG24" and spinup):
+        blocks.append("IMPORT_INST")
+    if source == "ONLINE_AVG24":
+        blocks.append("IMPORT_24")
+    if source == "PRECOMPUTED":
+        blocks.append("IMPORT_PRECOMPUTED")
+    for b in blocks:
+        out += [row("IMPORT", r) for r in golden["conditional_imports"][b]]
+    assert len(dict(out)) == len(out)
+    return dict(out)
+
+
+def registered_specs(path):
+    got = {}
+    for line in open(path):
+        inst, state, name, dims, vloc, restart, refresh, averaging, ungridded, a2e, units, long_name = line.rstrip("\n").split("|")
+        got.setdefault(inst, {})[(state, name)] = (int(dims), int(vloc), int(restart), int(refresh), int(averaging),
+                                                   int(ungridded), a2e.strip() == "T", units, long_name.rstrip())
+    return got
+
+
+@pytest.mark.parametrize("source,spinup", [("PRECOMPUTED", False), ("ONLINE_INST", False), ("ONLINE_AVG24", False),
+                                           ("ONLINE_AVG24", True)])
+def test_setservices_registers_the_reference_spec_table(tmp_path, small_model, source, spinup):
+    """Every field the reference's OH SetServices registers - the rows of OH_StateSpecs.rc and the ADD_IMPORT_* lines of
+    OH_GridCompMod.F90:611-634,693-783, as tests/golden/oh_specs.json holds them - is registered by the product's with
+    the same short name, dims, vlocation, restart, refresh / averaging interval, ungridded dimension, units and long
+    name, for a computational instance under every OH_data_source (with and without spin-up) and for a data-driven
+    instance beside it; and nothing else is."""
+    import json
+    golden = json.load(open(os.path.join(helpers.GOLDEN, "oh_specs.json")))
+    grid = (3, 3, 8)
+    imports, lats, lons = mock_imports(grid, "ONLINE_INST")
+    state, out = tmp_path / "state.bin", tmp_path / "out.bin"
+    write_state_file(state, grid, imports, lats, lons)
+    rundir = tmp_path / "run"
+    write_rundir(rundir, source=source, spinup=spinup, model_pattern="/nonexistent", exports=[], passive="OH.data")
+    with open(rundir / "AGCM.rc", "a") as f:
+        f.write(f"SPEC_DUMP: {tmp_path / 'specs.txt'}\n")
+    r = run_driver(DRIVER_ORACLE, rundir, state, out, 0)
+    assert r.returncode == 0, r.stdout[-2000:]
+    got = registered_specs(tmp_path / "specs.txt")
+    assert set(got) == {"OH", "OH.data"}
+    for inst, want in (("OH", expected_specs(golden, source, spinup)), ("OH.data", expected_specs(golden, None, False))):
+        assert set(got[inst]) == set(want), (inst, sorted(set(got[inst]) ^ set(want)))
+        for key in want:
+            assert got[inst][key] == want[key], (inst, key, got[inst][key], want[key])

@@ -1,8 +1,10 @@
 """The GridComp shell is written against MAPL and ESMF by their own names (north_star: "keeping
-the MAPL/ESMF GridComp surface ... so it drops into GEOS unchanged"): quickchem_amd/fortran/oh_gridcomp.F90 and
-quickchem_gridcomp.F90 `use ESMF`, `use MAPL`, include MAPL_Generic.h, and call nothing of the mock in
-quickchem_amd/fortran/mapl_lite/ that is not a real MAPL/ESMF name.  What they run on here (the mock) is tested by
-tests/test_gridcomp.py; this file pins the surface.
+the MAPL/ESMF GridComp surface ... so it drops into GEOS unchanged"): quickchem_amd/fortran/oh_gridcomp.F90 does
+`use ESMF`, `use MAPL`, includes MAPL_Generic.h, and calls nothing of the mock in quickchem_amd/fortran/mapl_lite/
+that is not a real MAPL/ESMF name.  (The parent above it is not in this repository at all: it is the reference's own
+QuickChem_GridCompMod.F90, compiled in place against the same mock - oracle/Makefile `ref` - which is the other half
+of "the mock speaks MAPL".)  What the shell runs on here (the mock) is tested by tests/test_gridcomp.py; this file pins
+the surface.
 Reference: OH_GridComp/OH_GridCompMod.F90:1,13-14,516-605,693-797,855-897,1147-1185,1195,1820,1860-1886;
 QuickChem_GridCompMod.F90:1,116-192,244-273,324-339,392-419,457-474,531."""
 import os
@@ -11,7 +13,17 @@ import re
 from tests import helpers
 
 FORTRAN = os.path.join(helpers.ROOT, "quickchem_amd", "fortran")
-SHELL = [os.path.join(FORTRAN, "oh_gridcomp.F90"), os.path.join(FORTRAN, "quickchem_gridcomp.F90")]
+SHELL = [os.path.join(FORTRAN, "oh_gridcomp.F90")]
+
+
+def test_the_parent_is_not_in_this_repository():
+    """QuickChem_GridCompMod is QuickChem's own file (the re-typed parent was a copy): nothing under the
+    package defines that module; the test driver uses it from oracle/_ref."""
+    for dirpath, _, names in os.walk(os.path.join(helpers.ROOT, "quickchem_amd")):
+        for name in names:
+            if name.lower().endswith((".f90", ".f")):
+                text = open(os.path.join(dirpath, name), errors="replace").read()
+                assert not re.search(r"^\s*module\s+QuickChem_GridCompMod\b", text, flags=re.I | re.M), name
 
 # every MAPL_ / ESMF_ identifier the reference's two grid components use (the lines above), plus MAPL_VLocationNone
 # (MAPL's constant for 2-D fields, which the reference leaves to the default)

@@ -57,3 +57,22 @@ def test_default_walk_kernel_shape(isa):
 def test_fields_kernel_reads_its_table_from_lds_too(isa):
     body = kernel_body(isa, "predict_fields_kernelILi2ELi2ELb1E")
     assert body.count("ds_read_b128") >= 4
+
+
+@pytest.mark.parametrize("kernel", ["predict_rows_ring_kernel", "predict_fields_ring_kernel"])
+def test_ring_kernels_shape(isa, kernel):
+    """The ring kernels (tree tops resident in LDS): the first four steps of four chains are ds_read_b128 (with and
+    without missing values: 2 x 4 x 4), the deep steps one buffer_load_dwordx4 per chain, the staging is LDS-DMA
+    (`buffer_load_dwordx4 ... lds`, eleven per group, for group 0 and in the loop), the claim is an LDS
+    compare-and-swap, there is ONE s_barrier (behind group 0), no scratch, and at most 128 VGPRs (16 waves per CU)."""
+    body = kernel_body(isa, kernel)
+    assert body.count("ds_read_b128") >= 32
+    dma = len(re.findall(r"buffer_load_dwordx4 [^\n]* lds", body))
+    assert dma == 22, dma
+    assert body.count("buffer_load_dwordx4") - dma >= 8
+    assert body.count("ds_cmpst_rtn_b32") == 1
+    assert body.count("s_barrier") == 1
+    assert "ds_bpermute_b32" not in body or kernel == "predict_rows_ring_kernel"     # (the rows' pieces use it; the walk does not)
+    vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", body).group(1))
+    assert vgpr <= 128, vgpr
+    assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", body).group(1)) == 0
