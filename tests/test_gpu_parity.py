@@ -820,7 +820,7 @@ def test_ring_rows_in_no_order(torch_cuda, deep_model):
 def test_ring_fused_fields_vs_oracle(torch_cuda, deep_model, dynamic):
     """The fused call on a slab big enough for predict_fields_ring_kernel (>= two residencies of the chip), with -999.0 and
     NaN in the fields, the rows that hold them listed for the second launch or walked in place; margins bit for bit."""
-    grid = (96, 72, 80)
+    grid = (144, 96, 80)
     pl, tropp, fields = helpers.synth_state(grid)
     rng = np.random.default_rng(23)
     fields = [f.copy() for f in fields]
