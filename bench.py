@@ -199,7 +199,9 @@ def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
                       f"10**pred; OH_GridCompMod.F90:308-374) linked against oracle/xgb_oracle.c, OMP_NUM_THREADS={cores} "
                       f"pinned (OMP_PROC_BIND=spread OMP_PLACES=cores; gather and 10** single-threaded as in the "
                       f"reference); {len(t_all)} ticks in one process, value = the fastest tick after the first "
-                      f"({steady:.2f} s); libxgboost 1.6.0 itself is not available here",
+                      f"({steady:.2f} s); libxgboost 1.6.0 itself is not available here.  All cores give about ten times "
+                      f"one thread, not {cores} times: the walk is bound by memory latency on the booster's 112 MB of raw "
+                      f"nodes, far beyond the caches - a baseline, not a measure of the GPU kernel (that is roofline.frac)",
             "ticks_s": [round(t, 4) for t in t_all],
             "first_tick_s": round(t_all[0], 4),
             "load_s": round(max(t_all[0] - steady, 0.0), 4),
@@ -345,6 +347,12 @@ def bench_run1(args, grid, n_total, model, booster, dev, t_model):
     per_step = (time.perf_counter() - t0) / args.steps
     booster.check()
     nslab = plane * (k2.value - k1.value + 1)
+    # ALGORITHMIC bytes of a Run1 tick: every import read once (3 edge fields, 28 layer fields - T, Q, TAUCLW, TAUCLI, seven
+    # scattering coefficients, sixteen features used as they are, the default OH - and six 2-D fields), INTERNAL OH
+    # and OH_boost written once, the booster's nodes once
+    info = booster.info()
+    algo = 4 * (3 * edge + 28 * vol + 6 * plane + 2 * vol) + info["node_bytes"]
+    achieved = algo / per_step / 1e9
     print(json.dumps({
         "metric": "OH gridcells/sec (XGBoost predict), C360 L72 batch", "value": nslab / per_step,
         "unit": "gridcells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
@@ -352,7 +360,12 @@ def bench_run1(args, grid, n_total, model, booster, dev, t_model):
         "config": {"workload": f"{args.grid} L{km}: OH Run1 imports -> INTERNAL OH in HBM (feature engineering, "
                                f"k-slab {k1.value}..{k2.value}, predict, tropopause mask, unit conversion)",
                    "grid": list(grid), "rows_predicted": nslab, "kernel": args.kernel, "params": args.param},
-        "roofline": None, "cpu_baseline": None}), flush=True)
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes": algo, "kernel_ms": per_step * 1e3,
+                     "kernel": "OHXBoosterRun1Device: feature_pointwise_kernel, feature_column_sums_reg_kernel<72>, k_slab_kernel, "
+                               + booster.fields_kernel_symbol(nslab) + ", post_process_kernel",
+                     "per": "tick = all kernels of one OH Run1 from the imports to INTERNAL OH (wall clock over the timed ticks)"},
+        "cpu_baseline": None}), flush=True)
 
 
 def measured_traffic(grid_name, kernel, model_nodes):
@@ -440,7 +453,7 @@ def bench_fields(args, grid, n_total, model, booster, dev, t_model):
                    "booster": {"trees": info["num_trees"], "nodes": info["num_nodes"], "node_bytes": info["node_bytes"],
                                "build_s": round(t_model, 2)}},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "predict_fields_kernel<2,2>",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": booster.fields_kernel_symbol(n_total),
                      "kernel_ms": per_step * 1e3, "algorithmic_bytes": algo},
         "cpu_baseline": None}), flush=True)
 

@@ -359,6 +359,17 @@ class Booster:
         check(self.lib, self.lib.OHXBoosterKernelSymbol(self.handle, ncol, C.byref(out)))
         return out.value.decode()
 
+    def fields_kernel_symbol(self, nrow: int = 1 << 30) -> str:
+        """The __global__ the fused OHXBoosterPredictFields launches for a slab of `nrow` gridcells: the fields kernel of
+        the same family as the rows kernel (kernels.hip launch_predict_fields; the ring kernel from two residencies
+        of the chip on)."""
+        import re
+        rows = self.kernel_symbol(27)
+        if "ring" in rows:
+            return "predict_fields_ring_kernel" if nrow >= 256 * 16 * 64 * 2 else "predict_fields_kernel<2,2,true>"
+        m = re.match(r"predict_rows_tile_kernel<(\d+),(\d+),(?:true|false),(true|false)>", rows)
+        return f"predict_fields_kernel<{m.group(1)},{m.group(2)},{m.group(3)}>" if m else "predict_fields_kernel<0,1,false>"
+
     def free(self) -> None:
         if self.handle:
             check(self.lib, self.lib.XGBoosterFree(self.handle))

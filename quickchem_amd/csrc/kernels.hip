@@ -1498,6 +1498,36 @@ __global__ __launch_bounds__(kBlock) void feature_column_sums_kernel(PrepArgs a,
   }
 }
 
+// The same with the column in registers (KM known at compile time): the O(km^2) additions of the SUM(x(k:km)) sums
+// are then VALU work on registers (2 628 adds per column at 72 levels) instead of as many LDS reads, and the column's
+// loads are all in flight together - 0.79 ms -> see profiles/r04_sweeps.txt.  Same order of additions, same bits.
+template <int KM>
+__global__ __launch_bounds__(kBlock) void feature_column_sums_reg_kernel(PrepArgs a, const float* __restrict__ aod) {
+#pragma clang fp contract(off)
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t col = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (col >= plane) return;
+  const float* src = (blockIdx.y == 0 ? a.tauclw : (blockIdx.y == 1 ? a.taucli : aod)) + col;
+  float* up = (blockIdx.y == 0 ? a.tauclwup : (blockIdx.y == 1 ? a.taucliup : a.aodup)) + col;
+  float* dn = (blockIdx.y == 0 ? a.tauclwdn : (blockIdx.y == 1 ? a.tauclidn : a.aoddn)) + col;
+  float x[KM];
+#pragma unroll
+  for (int k = 0; k < KM; ++k) x[k] = __builtin_nontemporal_load(src + plane * (uint64_t)k);
+  float run = 0.0f;
+#pragma unroll
+  for (int k = 0; k < KM; ++k) {
+    run = run + x[k];                                                          // SUM(x(1:k))
+    __builtin_nontemporal_store(run, up + plane * (uint64_t)k);
+  }
+#pragma unroll
+  for (int k = 0; k < KM; ++k) {                                               // SUM(x(k:km)), from zero
+    float s = 0.0f;
+#pragma unroll
+    for (int kk = k; kk < KM; ++kk) s = s + x[kk];
+    __builtin_nontemporal_store(s, dn + plane * (uint64_t)k);
+  }
+}
+
 // ksubcount = max over columns of COUNT(pl > tropp | tropp_min) (:275-298)
 __global__ __launch_bounds__(kBlock) void k_slab_kernel(SlabArgs a) {
 #pragma clang fp contract(off)
@@ -2041,6 +2071,11 @@ hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_
   if (plane == 0 || a.km <= 0) return hipSuccess;
   hipLaunchKernelGGL(feature_pointwise_kernel, dim3(grid_for(plane * (uint64_t)a.km, 256, 16)), dim3(kBlock), 0, stream,
                      a, aod_scratch);
+  if (a.km == 72) {        // GEOS's 72 levels: the column in registers
+    hipLaunchKernelGGL(feature_column_sums_reg_kernel<72>, dim3((unsigned)((plane + kBlock - 1) / kBlock), 3), dim3(kBlock), 0,
+                       stream, a, (const float*)aod_scratch);
+    return hipGetLastError();
+  }
   const size_t lds = (size_t)kWavesPerBlock * a.km * kWave * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   hipError_t e = ensure_lds(feature_column_sums_kernel, lds);

@@ -39,7 +39,7 @@ def main():
                    "FETCH_SIZE calibrated on this kernel's own row stream (see tools/make_traffic_json.py), WRITE_SIZE as read; "
                    "Infinity-Cache hits included (upper bound on HBM bytes).",
         "workload": line["config"]["grid"] and "C360" if line["config"]["grid"] == [360, 2160, 72] else str(line["config"]["grid"]),
-        "kernel": "super2", "model_nodes": line["config"]["booster"]["nodes"],
+        "kernel": "ring", "model_nodes": line["config"]["booster"]["nodes"],
         "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "fetch_calibration": round(scale, 4),
         "traffic_bytes_per_step": round(traffic), "kernel_source_hash": bench_py.kernel_source_hash(),
         "kernel_ms_when_measured": line["roofline"]["kernel_ms"]}, indent=1))

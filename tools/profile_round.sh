@@ -13,10 +13,14 @@ grep "^{\"metric\"" $O/bench_under_rocprof.log | tail -1 > $O/bench.json
 cp $O/trace/*/*_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 timeout -k 10 600 python3 bench.py > $O/bench_plain.log 2>&1
 grep "^{\"metric\"" $O/bench_plain.log | tail -1 > $O/bench_plain.json
-PMC_KERNEL='predict_rows_tile_kernel<2, 2, true, true>' tools/pmc.sh $tag > /dev/null 2>&1
+# the same with nothing but the timed region launching the walk kernel (no pcie_inclusive leg, no CPU leg)
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace2 -- python3 bench.py --no-pcie --cpu-seconds 0 > $O/bench_under_rocprof_timed_only.log 2>&1
+grep "^{\"metric\"" $O/bench_under_rocprof_timed_only.log | tail -1 > $O/bench_timed_only.json
+cp $O/trace2/*/*_kernel_stats.csv $O/kernel_stats_timed_only.csv 2>/dev/null
+PMC_KERNEL="${WALK_KERNEL:-predict_rows_ring_kernel}" tools/pmc.sh $tag > /dev/null 2>&1
 cp gpurun_out/pmc_$tag/summary.txt $O/pmc_summary.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/calib_$c -- python3 bench.py --cpu-seconds 0 --no-verify --steps 2 --warmup 1 --trees 1 --depth 0 > $O/calib_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/calib_$c -- python3 bench.py --cpu-seconds 0 --no-verify --steps 2 --warmup 1 --trees 1 --depth 0 --kernel ring > $O/calib_$c.log 2>&1
 done
 python3 - $O <<'PY'
 import csv, glob, sys
@@ -26,7 +30,7 @@ with open(O + '/calib_fetch_write.txt', 'w') as out:
         tot = 0.0
         for f in glob.glob(f'{O}/calib_{c}/*/*_counter_collection.csv'):
             for r in csv.DictReader(open(f)):
-                if 'predict_rows_tile_kernel<2, 2, true' in r['Kernel_Name'] and r['Counter_Name'] == c:
+                if 'predict_rows_ring_kernel' in r['Kernel_Name'] and r['Counter_Name'] == c:
                     tot += float(r['Counter_Value'])
         line = f"{c} per_step={tot/3:.6g} (1 tree of depth 0: rows 6 046 617 600 B read, 223 948 800 B written per step)"
         print(line); out.write(line + "\n")
@@ -36,5 +40,5 @@ python3 tools/make_traffic_json.py $O/pmc_summary.txt $O/calib_fetch_write.txt $
 cp $O/traffic.json profiles/${tag}_traffic.json
 timeout -k 10 600 python3 bench.py > $O/bench_plain.log 2>&1
 grep "^{\"metric\"" $O/bench_plain.log | tail -1 > $O/bench_plain.json
-rm -rf $O/trace $O/calib_FETCH_SIZE $O/calib_WRITE_SIZE
+rm -rf $O/trace $O/trace2 $O/calib_FETCH_SIZE $O/calib_WRITE_SIZE
 ls -la $O
