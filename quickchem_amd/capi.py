@@ -302,13 +302,14 @@ class Booster:
             self.handle, ptrs, flags, nf, pl_feature, im, jm, km, k1, k2, missing, 1 if apply_pow10 else 0, ohscale,
             oh_ml_ptr, margin_ptr or None, stream or None))
 
-    def run1(self, state: dict, *, dynamic_k_range: bool, tropp_min: float = 4000.0, ohscale: float = 0.85,
-             missing: float = -999.0, avogad: float = 6.023e26, runiv: float = 8314.47,
-             epsilon: float = 18.015 / 28.965, want_boost: bool = True, want_ndwet: bool = True,
-             want_diag: bool = False) -> dict:
-        """OHXBoosterRun1 on host arrays.  `state` maps the names of OHXRun1Args to [i,j(,k)]-indexed
-        float32 arrays (edge fields have km+1 levels; "scacoef" is a list of seven).  Returns
-        {"oh", "oh_boost", "ndwet", "k1", "k2"} with arrays indexed [i,j,k]."""
+    def run1_prepare(self, state: dict, *, dynamic_k_range: bool, tropp_min: float = 4000.0, ohscale: float = 0.85,
+                     missing: float = -999.0, avogad: float = 6.023e26, runiv: float = 8314.47,
+                     epsilon: float = 18.015 / 28.965, want_boost: bool = True, want_ndwet: bool = True,
+                     want_diag: bool = False) -> dict:
+        """The OHXRun1Args of a tick, built once: `state` maps the names of OHXRun1Args to [i,j(,k)]-indexed float32
+        arrays (edge fields have km+1 levels; "scacoef" is a list of seven).  The returned call keeps the flattened
+        host arrays alive at fixed addresses - as MAPL's state pointers are from tick to tick - so that run1_call can
+        be repeated on them (and ohx_register_host has something stable to register)."""
         def flat(a):
             return np.ascontiguousarray(np.asarray(a, dtype=np.float32).T)
         im, jm, km = state["t_mod"].shape
@@ -340,12 +341,24 @@ class Booster:
                 setattr(args, name, diag[name].ctypes.data)
             diag["diag_strato3"] = np.zeros(im * jm, dtype=np.float32)
             args.diag_strato3 = diag["diag_strato3"].ctypes.data
-        check(self.lib, self.lib.OHXBoosterRun1(self.handle, C.byref(args)))
+        return {"args": args, "keep": keep, "oh": oh, "boost": boost, "ndwet": ndwet, "k1": k1, "k2": k2, "diag": diag,
+                "shape": (im, jm, km)}
+
+    def run1_call(self, call: dict) -> dict:
+        """OHXBoosterRun1 on the host arrays of a prepared call.  Returns {"oh", "oh_boost", "ndwet", "k1", "k2"} (+ the
+        DIAG dumps) as views of the call's output arrays, indexed [i,j,k]."""
+        im, jm, km = call["shape"]
+        check(self.lib, self.lib.OHXBoosterRun1(self.handle, C.byref(call["args"])))
         unflat = lambda a: None if a is None else a.reshape(km, jm, im).transpose(2, 1, 0)   # noqa: E731
-        out = {"oh": unflat(oh), "oh_boost": unflat(boost), "ndwet": unflat(ndwet), "k1": k1.value, "k2": k2.value}
-        for name, a in diag.items():
+        out = {"oh": unflat(call["oh"]), "oh_boost": unflat(call["boost"]), "ndwet": unflat(call["ndwet"]),
+               "k1": call["k1"].value, "k2": call["k2"].value}
+        for name, a in call["diag"].items():
             out[name] = a.reshape(jm, im).T if name == "diag_strato3" else unflat(a)
         return out
+
+    def run1(self, state: dict, **kw) -> dict:
+        """OHXBoosterRun1 on host arrays (run1_prepare + run1_call)."""
+        return self.run1_call(self.run1_prepare(state, **kw))
 
     def info(self) -> dict:
         arr = (C.c_uint64 * 8)()

@@ -14,7 +14,9 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <atomic>
 #include <mutex>
+#include <unordered_map>
 #include <sstream>
 #include <string>
 #include <unordered_set>
@@ -218,6 +220,107 @@ struct RowPool {
   }
 };
 RowPool g_row_pool;
+
+// The caller's host arrays, registered with the driver (ohx_register_host = 1; include/ohxgb.h part 2).
+//
+// The host forms of the fused calls copy some forty arrays per OH tick (OHXBoosterRun1: 37 inputs, up to 12 outputs).
+// From pageable memory every one of those copies is a staged, synchronous transfer: on a GEOS-sized rank block
+// (48 x 24 x 72) they cost more than the prediction (profiles/r04_ranks_per_gpu*.json).  A registered (pinned) array
+// is read and written by the GPU's DMA engines directly and `hipMemcpyAsync` returns at once.  Registration costs
+// about as much as ten ticks and is done once per array: (pointer, bytes) is remembered, and MAPL's import, export
+// and internal pointers are the same from tick to tick (OH_GridCompMod.F90:1136,1195: MAPL_GetPointer on states that
+// live as long as the run).  It is OPT-IN because it is a contract: an array that was passed while this is on must
+// stay allocated until OHXReleaseScratch() or the end of the process - memory that is freed and handed out again at
+// the same address would still be reached through the old registration.  What the driver refuses to register
+// (it happens to ranges that share a page with another registration) is copied the pageable way as before.
+struct HostRegistry {
+  std::mutex mu;
+  std::atomic<bool> on{false};
+  std::unordered_map<const void*, size_t> pinned;     // base -> bytes, registered by us
+  std::unordered_map<const void*, size_t> refused;    // base -> bytes the driver would not take
+  size_t bytes = 0;
+  // true when [p, p + n) is registered afterwards
+  bool want(const void* p, size_t n) {
+    if (!on.load(std::memory_order_relaxed) || p == nullptr || n == 0) return false;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = pinned.find(p);
+    if (it != pinned.end()) {
+      if (it->second >= n) return true;
+      (void)hipHostUnregister(const_cast<void*>(p));      // the same array, grown: again from the start
+      bytes -= it->second;
+      pinned.erase(it);
+    }
+    auto rf = refused.find(p);
+    if (rf != refused.end() && rf->second == n) return false;
+    if (hipHostRegister(const_cast<void*>(p), n, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      refused[p] = n;
+      return false;
+    }
+    pinned[p] = n;
+    bytes += n;
+    return true;
+  }
+  void release_all() {
+    std::lock_guard<std::mutex> g(mu);
+    if (getenv("OHX_REGISTRY_LOG") && (!pinned.empty() || !refused.empty()))
+      fprintf(stderr, "[ohxgb] host registry: %zu arrays (%zu bytes) registered, %zu refused\n", pinned.size(), bytes,
+              refused.size());
+    for (auto& kv : pinned) (void)hipHostUnregister(const_cast<void*>(kv.first));
+    pinned.clear();
+    refused.clear();
+    bytes = 0;
+  }
+};
+HostRegistry g_host_registry;
+
+// Host arrays <-> HBM for the host forms of the fused calls.  Arrays the registry holds are gathered into ONE launch of
+// copy_arrays_kernel (the GPU reads or writes the caller's memory over PCIe itself) as long as the whole list is
+// small - a rank-sized block, where forty separate copies cost forty fixed prices; big lists and arrays that are not
+// registered go through hipMemcpyAsync.
+struct HostMover {
+  static constexpr size_t kKernelBytesMax = 64u << 20;
+  CopyList list;
+  size_t list_bytes = 0;
+  hipStream_t stream;
+  bool to_device;
+  explicit HostMover(hipStream_t s, bool h2d) : stream(s), to_device(h2d) {}
+  void add(float* dst, const float* src, size_t count) {
+    if (count == 0) return;
+    const void* host = to_device ? (const void*)src : (const void*)dst;
+    void* mapped = nullptr;
+    if (g_host_registry.want(host, count * sizeof(float)) && list.count < kCopyListMax &&
+        list_bytes + count * sizeof(float) <= kKernelBytesMax &&
+        hipHostGetDevicePointer(&mapped, const_cast<void*>(host), 0) == hipSuccess && mapped != nullptr) {
+      list.src[list.count] = to_device ? static_cast<const float*>(mapped) : src;
+      list.dst[list.count] = to_device ? dst : static_cast<float*>(mapped);
+      list.n[list.count] = count;
+      ++list.count;
+      list_bytes += count * sizeof(float);
+      return;
+    }
+    (void)hipGetLastError();
+    HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(float), to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream));
+  }
+  void go() {
+    HIP_CHECK(launch_copy_arrays(list, stream));
+    list.count = 0;
+    list_bytes = 0;
+  }
+};
+
+// host -> device, through the registry when it is on (then asynchronous on `stream`), the pageable way otherwise
+void upload_host_array(float* dst, const float* src, size_t count, hipStream_t stream) {
+  if (count == 0) return;
+  (void)g_host_registry.want(src, count * sizeof(float));
+  HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyHostToDevice, stream));
+}
+// device -> host; the caller synchronises `stream` before it looks at dst
+void download_host_array(float* dst, const float* src, size_t count, hipStream_t stream) {
+  if (count == 0) return;
+  (void)g_host_registry.want(dst, count * sizeof(float));
+  HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, stream));
+}
 
 // Flag and verdict words of the matrix checks (inf scan, level-size search): one device buffer and one pinned
 // host mirror per process, so that a check is launches + ONE read-back.
@@ -1066,6 +1169,10 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     b->tune.cluster_steps = std::max(1, atoi(value));
   } else if (n == "ohx_lds_pad") {
     b->tune.lds_pad = atoi(value);
+  } else if (n == "ohx_register_host") {
+    // process-wide (the host form of OHXOHPostProcess has no booster): see HostRegistry
+    g_host_registry.on.store(atoi(value) != 0);
+    if (atoi(value) == 0) g_host_registry.release_all();
   } else if (n == "ohx_ring_rounds") {
     b->tune.ring_rounds = atoi(value);
     if (b->tune.ring_rounds < 0) throw OhxError("ohx_ring_rounds must be >= 0");
@@ -1225,7 +1332,9 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
     b->d_stage[(size_t)f].ensure(is2d[f] ? plane : nrow);
     a.field[f] = b->d_stage[(size_t)f].p;
     if (is2d[f])
-      HIP_CHECK(hipMemcpyAsync(b->d_stage[(size_t)f].p, fields[f], plane * sizeof(float), hipMemcpyHostToDevice, b->s_copy));
+      upload_host_array(b->d_stage[(size_t)f].p, fields[f], plane, b->s_copy);
+    else if (g_host_registry.on.load(std::memory_order_relaxed))
+      (void)g_host_registry.want(fields[f], plane * (size_t)km * sizeof(float));       // the whole field once, not per piece
   }
   a.src_k0 = a.k1;
   a.out_k0 = a.k1;
@@ -1266,6 +1375,10 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
     const bool deferring = nfield == 27 && defer_prepare(*b, piece_rows, tune);
     HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), piece, b->dev.num_cus, b->s_exec, tune));
     if (deferring) defer_look(*b, piece_rows, b->s_exec);
+  }
+  if (g_host_registry.on.load(std::memory_order_relaxed)) {
+    (void)g_host_registry.want(oh_ml, plane * (size_t)km * sizeof(float));
+    if (margin) (void)g_host_registry.want(margin, nrow * sizeof(float));
   }
   HIP_CHECK(hipMemcpyAsync(oh_ml + plane * (size_t)a.k1, b->d_stage_out.p, nrow * sizeof(float), hipMemcpyDeviceToHost,
                            b->s_exec));
@@ -1422,17 +1535,22 @@ int OHXOHPostProcess(int im, int jm, int km, float avogad, float runiv, float ep
   }
   const float* src[6] = {ple_mod, t_mod, q_mod, tropp_mod, default_oh, oh_ml};
   const size_t n[6] = {edge, vol, vol, plane, vol, vol};
+  HostMover in(nullptr, true);
   for (int i = 0; i < 6; ++i) {
     g_post.buf[i].ensure(n[i]);
-    HIP_CHECK(hipMemcpyAsync(g_post.buf[i].p, src[i], n[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    in.add(g_post.buf[i].p, src[i], n[i]);
   }
+  in.go();
   g_post.buf[6].ensure(vol);
   if (ndwet) g_post.buf[7].ensure(vol);
   HIP_CHECK(launch_post_process(post_args(im, jm, km, avogad, runiv, epsilon, g_post.buf[0].p, g_post.buf[1].p,
                                           g_post.buf[2].p, g_post.buf[3].p, g_post.buf[4].p, g_post.buf[5].p,
                                           g_post.buf[6].p, ndwet ? g_post.buf[7].p : nullptr), nullptr));
-  HIP_CHECK(hipMemcpy(oh, g_post.buf[6].p, vol * sizeof(float), hipMemcpyDeviceToHost));
-  if (ndwet) HIP_CHECK(hipMemcpy(ndwet, g_post.buf[7].p, vol * sizeof(float), hipMemcpyDeviceToHost));
+  HostMover back(nullptr, false);
+  back.add(oh, g_post.buf[6].p, vol);
+  if (ndwet) back.add(ndwet, g_post.buf[7].p, vol);
+  back.go();
+  HIP_CHECK(hipStreamSynchronize(nullptr));
   API_END();
 }
 
@@ -1521,12 +1639,14 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
       {h.sza, &d.sza, plane}, {h.default_oh, &d.default_oh, vol}};
   const size_t nin = sizeof(ins) / sizeof(ins[0]);
   if (b->d_run1_stage.size() < nin + 3 + 9) b->d_run1_stage.resize(nin + 3 + 9);
+  HostMover in(nullptr, true);
   for (size_t i = 0; i < nin; ++i) {
     if (ins[i].host == nullptr) throw OhxError("OHXBoosterRun1: a required field pointer is NULL");
     b->d_run1_stage[i].ensure(ins[i].n);
-    HIP_CHECK(hipMemcpyAsync(b->d_run1_stage[i].p, ins[i].host, ins[i].n * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    in.add(b->d_run1_stage[i].p, ins[i].host, ins[i].n);
     *ins[i].dev = b->d_run1_stage[i].p;
   }
+  in.go();
   if (h.oh == nullptr) throw OhxError("OHXBoosterRun1: oh is NULL");
   b->d_run1_stage[nin].ensure(vol);
   d.oh = b->d_run1_stage[nin].p;
@@ -1555,12 +1675,14 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
     *outs[i].dev = b->d_run1_stage[nin + 3 + i].p;
   }
   run1_device(*b, d, nullptr);
-  HIP_CHECK(hipMemcpy(h.oh, d.oh, vol * sizeof(float), hipMemcpyDeviceToHost));
-  if (h.ndwet) HIP_CHECK(hipMemcpy(h.ndwet, d.ndwet, vol * sizeof(float), hipMemcpyDeviceToHost));
-  if (h.oh_boost) HIP_CHECK(hipMemcpy(h.oh_boost, d.oh_boost, vol * sizeof(float), hipMemcpyDeviceToHost));
+  HostMover back(nullptr, false);
+  back.add(h.oh, d.oh, vol);
+  if (h.ndwet) back.add(h.ndwet, d.ndwet, vol);
+  if (h.oh_boost) back.add(h.oh_boost, d.oh_boost, vol);
   for (size_t i = 0; i < nout; ++i)
-    if (outs[i].host) HIP_CHECK(hipMemcpy(outs[i].host, *outs[i].dev, outs[i].n * sizeof(float), hipMemcpyDeviceToHost));
-  raise_flag_errors(*b, nullptr);
+    if (outs[i].host) back.add(outs[i].host, *outs[i].dev, outs[i].n);
+  back.go();
+  raise_flag_errors(*b, nullptr);          // waits for the stream: the outputs are in the caller's arrays
   API_END();
 }
 
@@ -1623,6 +1745,7 @@ int OHXBoosterKernelSymbol(BoosterHandle handle, bst_ulong ncol, const char** ou
 int OHXReleaseScratch(void) {
   API_BEGIN();
   g_row_pool.release_all();
+  g_host_registry.release_all();
   {
     std::lock_guard<std::mutex> g(g_post.mu);
     for (auto& bf : g_post.buf) bf.release();

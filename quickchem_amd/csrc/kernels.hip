@@ -757,12 +757,19 @@ __device__ __forceinline__ void ring_order() { asm volatile("s_waitcnt lgkmcnt(0
 // (range-checked), to LDS at lds_addr + 16 * lane.  In assembly because hipcc puts `s_waitcnt vmcnt(0)` in front of
 // every LDS read that follows a DMA it knows of; the caller waits (vmcnt) before anybody reads what it wrote.
 __device__ __forceinline__ void dma_to_lds_b128(u32x4 desc, uint32_t off, uint32_t lds_addr) {
+#if defined(__gfx950__)
   uint32_t keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(off), "s"(desc), "s"(lds_addr)
       : "memory");
+#else
+  // 16-byte LDS-DMA is a gfx950 instruction; this library is built for nothing else (a sanitizer build of the HOST
+  // side drags a default device target along: it must compile, it never runs)
+  (void)desc; (void)off; (void)lds_addr;
+  __builtin_trap();
+#endif
 }
 
 // What a wave knows of its block's ring.
@@ -2104,6 +2111,38 @@ hipError_t launch_post_process(const PostArgs& a, hipStream_t stream) {
   const uint64_t total = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)a.km;
   if (total == 0) return hipSuccess;
   hipLaunchKernelGGL(post_process_kernel, dim3(grid_for(total, 256, 16)), dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
+}
+
+// Many arrays moved by ONE launch: array a of the list is copied by the blocks (*, a).  Either side may be the
+// caller's registered host memory, which the GPU reads and writes over PCIe directly (capi.cpp HostRegistry): forty
+// copies of a rank-sized block's arrays cost forty times a copy's fixed price, one launch costs one.
+__global__ __launch_bounds__(kBlock) void copy_arrays_kernel(CopyList l) {
+  const uint32_t a = blockIdx.y;
+  const float* __restrict__ src = l.src[a];
+  float* __restrict__ dst = l.dst[a];
+  const uint64_t n = l.n[a];
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+    const uint64_t n4 = n / 4;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (uint64_t i = t; i < n4; i += stride) d4[i] = s4[i];
+    for (uint64_t i = n4 * 4 + t; i < n; i += stride) dst[i] = src[i];
+  } else {
+    for (uint64_t i = t; i < n; i += stride) dst[i] = src[i];
+  }
+}
+
+hipError_t launch_copy_arrays(const CopyList& l, hipStream_t stream) {
+  if (l.count == 0) return hipSuccess;
+  uint64_t longest = 0;
+  for (uint32_t a = 0; a < l.count; ++a) longest = l.n[a] > longest ? l.n[a] : longest;
+  uint64_t blocks = (longest / 4 + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(copy_arrays_kernel, dim3((unsigned)blocks, l.count), dim3(kBlock), 0, stream, l);
   return hipGetLastError();
 }
 

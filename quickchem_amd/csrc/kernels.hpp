@@ -293,6 +293,16 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& forest, const Pre
                           hipStream_t stream, const LaunchTuning& tune = LaunchTuning());
 hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& forest, const FieldsArgs& a, int num_cus,
                                  hipStream_t stream, const LaunchTuning& tune = LaunchTuning());
+// up to kCopyListMax arrays moved by one launch (kernels.hip copy_arrays_kernel); pointers the device can reach
+constexpr uint32_t kCopyListMax = 48;
+struct CopyList {
+  const float* src[kCopyListMax];
+  float* dst[kCopyListMax];
+  uint64_t n[kCopyListMax];     // floats
+  uint32_t count = 0;
+};
+hipError_t launch_copy_arrays(const CopyList& l, hipStream_t stream);
+
 hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream);
 // Level-size search (capi.cpp infer_level_size): block (x, y) tests whether column cols.col[y] repeats with
 // period nrow / (kmax - x); d_verdict[y * (kmax - 1) + x] must be zero before and is 0 (periodic), 1 (not) or

@@ -270,3 +270,65 @@ def test_post_process_and_diag_dumps_on_the_gpu(small_model, grid):
     assert np.array_equal(helpers.bits(a[0]), helpers.bits(c[0])) and np.array_equal(helpers.bits(a[1]), helpers.bits(c[1]))
     with pytest.raises(capi.OhxError, match="NULL"):
         capi.check(b.lib, b.lib.OHXOHPostProcess(4, 4, 4, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None))
+
+
+@pytest.mark.gpu
+def test_host_forms_with_registered_arrays(small_model):
+    """ohx_register_host: the host forms of OHXBoosterRun1, OHXOHPostProcess and OHXBoosterPredictFields on arrays that
+    stay at their addresses from tick to tick (as MAPL's do) - registered with the driver at the first tick, gathered
+    into one copy launch from then on - give what they give on pageable arrays, bit for bit, tick after tick; arrays
+    that are not 16-byte aligned take the scalar lanes of the copy kernel; OHXReleaseScratch() forgets the
+    registrations and the next tick makes them again."""
+    import torch
+    torch.cuda.set_device(0)
+    grid = (37, 11, 40)
+    st = helpers.run1_state(grid, seed=3)
+    b = capi.Booster(model_buffer=small_model.image)
+    call = b.run1_prepare(st, dynamic_k_range=True, want_diag=True)
+    # one input at an address that is 4 but not 16 bytes aligned
+    shifted = np.zeros(call["keep"]["co"].size + 1, dtype=np.float32)[1:]
+    shifted[:] = call["keep"]["co"].reshape(-1)
+    assert shifted.ctypes.data % 16 != 0
+    call["keep"]["co_shifted"] = shifted
+    call["args"].co = shifted.ctypes.data
+    plain = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in b.run1_call(call).items()}
+    b.set_param("ohx_register_host", "1")
+    try:
+        for tick in range(3):
+            got = b.run1_call(call)
+            for k, v in plain.items():
+                if isinstance(v, np.ndarray):
+                    assert np.array_equal(helpers.bits(got[k]), helpers.bits(v)), (tick, k)
+                else:
+                    assert got[k] == v
+            if tick == 1:
+                capi.check(b.lib, b.lib.OHXReleaseScratch())
+        # the post-processing of a tick that skips Boost, host form
+        im, jm, km = grid
+        flat = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32).T)      # noqa: E731
+        ins = [flat(st[k]) for k in ("ple_mod", "t_mod", "q_mod", "tropp_mod", "default_oh")] + [flat(plain["oh_boost"])]
+        outs = {}
+        for mode in ("1", "0"):
+            b.set_param("ohx_register_host", mode)
+            oh, nd = np.zeros(im * jm * km, dtype=np.float32), np.zeros(im * jm * km, dtype=np.float32)
+            for _ in range(2):
+                capi.check(b.lib, b.lib.OHXOHPostProcess(im, jm, km, 6.023e26, 8314.47, 18.015 / 28.965,
+                                                         *[a.ctypes.data for a in ins], oh.ctypes.data, nd.ctypes.data))
+            outs[mode] = (oh, nd)
+        assert np.array_equal(helpers.bits(outs["1"][0]), helpers.bits(outs["0"][0]))
+        assert np.array_equal(helpers.bits(outs["1"][1]), helpers.bits(outs["0"][1]))
+        # the fused call, host form
+        g2 = synth.GRIDS["C12"]
+        pl, tropp, fields = helpers.synth_state(g2)
+        ff = [np.ascontiguousarray(f.T) for f in fields]
+        res = {}
+        for mode in ("1", "0"):
+            b.set_param("ohx_register_host", mode)
+            oh = np.zeros(g2[0] * g2[1] * g2[2], dtype=np.float32)
+            for _ in range(2):
+                b.predict_fields(ff, synth.IS2D, synth.PL_FEATURE, *g2, 5, g2[2], synth.XX_MISS, oh, ohscale=0.85)
+            res[mode] = oh
+        assert np.array_equal(helpers.bits(res["1"]), helpers.bits(res["0"])) and np.any(res["1"] != 0)
+    finally:
+        b.set_param("ohx_register_host", "0")
+        b.free()

@@ -9,6 +9,10 @@ Starts P fresh processes on ONE GPU, P in --ranks.  Each is a "rank" that owns C
    reference:  XGDMatrixCreateFromMat -> XGBoosterPredict -> XGDMatrixFree   (the booster made and loaded at the
                first tick, as predict_OH_with_XGB does: :242-271), and
    fused:      OHXBoosterPredictFields (gather, PL/100, walk, 10**, *OHscale in one call)
+   run1:       OHXBoosterRun1, the HOST form - the one call quickchem_amd/fortran/oh_gridcomp.F90 makes on a Boost tick
+               (oh_run1_boost: 37 import arrays in, INTERNAL OH, OH_boost and NDWET out; OH_GridCompMod.F90:1444-1595)
+   run1_registered:  the same with XGBoosterSetParam("ohx_register_host", "1"): the arrays are registered with the
+               driver at their first tick and read / written by DMA from then on
 from pageable numpy arrays.  The ranks start their ticks together (a start time handed to all of them).  Prints ONE JSON
 object: per P the aggregate gridcells/s over the common window, per-tick latency p50 / p95 / max, the first tick, and
 the HBM the processes hold together.
@@ -86,9 +90,33 @@ def child(args):
         ticks["fused"].append(time.perf_counter() - t0)
         ends["fused"].append(time.time())
     t_fused1 = time.time()
+    # OH Run1 through its host form, on the rank's block: a synthetic import state (tests/helpers.run1_state: plausible
+    # magnitudes), the arrays at fixed addresses from tick to tick as MAPL's state pointers are
+    from tests import helpers as test_helpers
+    st = test_helpers.run1_state(sub, seed=17 + args.rank)
+    call = b.run1_prepare(st, dynamic_k_range=True, want_boost=True, want_ndwet=True)
+    windows = {"reference": [t_ref0, t_ref1], "fused": [t_ref1, t_fused1]}
+    first_oh = None
+    for mode in ("run1", "run1_registered"):
+        ticks[mode], ends[mode] = [], []
+        b.set_param("ohx_register_host", "1" if mode == "run1_registered" else "0")
+        w0 = time.time()
+        for tick in range(args.ticks):
+            t0 = time.perf_counter()
+            r1 = b.run1_call(call)
+            ticks[mode].append(time.perf_counter() - t0)
+            ends[mode].append(time.time())
+        windows[mode] = [w0, time.time()]
+        if first_oh is None:
+            first_oh = r1["oh"].copy()
+        else:
+            assert np.array_equal(first_oh.view(np.uint32), r1["oh"].view(np.uint32)), "registered run1 differs"
+    out["run1_rows_predicted"] = int(im * jm * (r1["k2"] - r1["k1"] + 1))
+    out["run1_bytes_in"] = int(sum(a.nbytes for k, a in call["keep"].items() if k != "sca") + sum(a.nbytes for a in call["keep"]["sca"]))
+    b.set_param("ohx_register_host", "0")
     free_after, _ = hbm_free_bytes()
     same = bool(np.array_equal(oh.view(np.uint32), p.view(np.uint32)))      # both paths, same margins
-    out.update({"ticks_s": ticks, "tick_ends": ends, "window": {"reference": [t_ref0, t_ref1], "fused": [t_ref1, t_fused1]},
+    out.update({"ticks_s": ticks, "tick_ends": ends, "window": windows,
                 "paths_agree_bit_for_bit": same, "margin_sum": ref_sum,
                 "hbm_free_before": free_before, "hbm_free_after": free_after, "hbm_total": total})
     print("RANK_JSON " + json.dumps(out), flush=True)
@@ -139,7 +167,9 @@ def parent(args):
         held = [r["hbm_free_before"] - r["hbm_free_after"] for r in ranks if r["hbm_free_before"] is not None]
         if held:
             entry["hbm_held_all_ranks_bytes"] = max(r["hbm_free_before"] for r in ranks) - min(r["hbm_free_after"] for r in ranks)
-        for mode in ("reference", "fused"):
+        entry["run1_bytes_in_per_rank"] = ranks[0]["run1_bytes_in"]
+        entry["run1_rows_predicted_per_rank"] = ranks[0]["run1_rows_predicted"]
+        for mode in ("reference", "fused", "run1", "run1_registered"):
             first = [r["ticks_s"][mode][0] for r in ranks]
             later = [t for r in ranks for t in r["ticks_s"][mode][1:]]
             # the interval in which EVERY rank is ticking steadily: from the last rank's first tick's end to the
