@@ -1105,9 +1105,14 @@ int XGBoosterSaveModel(BoosterHandle handle, const char* fname) {
 
 int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value) {
   API_BEGIN();
-  BoosterObj* b = as_booster(handle);
   if (name == nullptr || value == nullptr) throw OhxError("XGBoosterSetParam: NULL argument");
   const std::string n(name), v(value);
+  if (n == "ohx_register_host" && handle == nullptr) {       // process-wide: settable before any booster exists
+    g_host_registry.on.store(atoi(value) != 0);
+    if (atoi(value) == 0) g_host_registry.release_all();
+    return 0;
+  }
+  BoosterObj* b = as_booster(handle);
   if (n == "ohx_kernel") {
     if (v != "auto" && v != "wide" && v != "packed1" && v != "packed2" && v != "packed4" && v != "super1" &&
         v != "super2" && v != "super3" && v != "super4" && v != "ring")

@@ -6,13 +6,13 @@
 !  text (oh_xgb_error_text of module oh_xgb_predict).
 module oh_run1
    use, intrinsic :: iso_c_binding
-   use ohx_bindings, only: ohx_last_error
+   use ohx_bindings, only: ohx_last_error, XGBoosterSetParam
    use oh_xgb_predict, only: oh_xgb_booster, OH_XGB_SUCCESS, OH_XGB_FAILURE
    implicit none
    private
 
    public :: OH_RUN1_STATE, OH_RUN1_DIAG, oh_run1_boost, oh_post_process, oh_solar_geometry, oh_julian_day
-   public :: oh_run1_error_text
+   public :: oh_run1_error_text, oh_run1_register_host_arrays
 
    !  struct OHXRun1Args, member for member
    type, bind(C) :: OHXRun1Args
@@ -250,6 +250,14 @@ contains
 
    !  The tropopause mask and the unit conversion alone (:1247-1257, 1579-1595), for a tick that does not call
    !  Boost (compute_once_per_day, :1189-1193): OH_ML is the persisted self%OH_ML, already scaled.
+   !  ohx_register_host (include/ohxgb.h): process-wide, no booster needed.  The caller promises that every array it hands
+   !  to the host forms from now on stays allocated until the end of the run.
+   subroutine oh_run1_register_host_arrays(on)
+      logical, intent(in) :: on
+      integer(c_int) :: rc
+      rc = XGBoosterSetParam(c_null_ptr, 'ohx_register_host'//c_null_char, merge('1', '0', on)//c_null_char)
+   end subroutine
+
    subroutine oh_post_process(im, jm, km, avogad, runiv, epsilon, PLE_MOD, T_MOD, Q_MOD, TROPP_MOD, default_OH, OH_ML, &
                               OH, NDWET, rc)
       integer, intent(in) :: im, jm, km

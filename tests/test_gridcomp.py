@@ -86,7 +86,7 @@ def write_state_file(path, grid, imports, lats, lons):
 
 def write_rundir(d, *, source, model_pattern, once_per_day=True, spinup=True, policy="reference", run_dt=1800,
                  oh_dt=3600, ref_time="003000", beg="20240131 000000", exports=(), avg24_tick=-1,
-                 active="OH", passive="", ohscale=0.85, wavelength=550):
+                 active="OH", passive="", ohscale=0.85, wavelength=550, register=False):
     os.makedirs(d, exist_ok=True)
     open(os.path.join(d, "AGCM.rc"), "w").write(
         f"# mock of the GEOS AGCM.rc keys OH reads\nRUN_DT: {run_dt}\nQUICKCHEM_DT: {run_dt}\nOH_DT: {oh_dt}\n"
@@ -98,7 +98,7 @@ def write_rundir(d, *, source, model_pattern, once_per_day=True, spinup=True, po
     open(os.path.join(d, "OH_instance_OH.rc"), "w").write(
         f"nbins: 1\nXGBoostFile: {model_pattern}\nOH_data_source: {source}\nspinup_24hr_imports: {'T' if spinup else 'F'}\n"
         f"wavelength_for_scacoef: {wavelength}\ncompute_once_per_day: {'T' if once_per_day else 'F'}\nOHscale: {ohscale}\n"
-        f"XGBoost_model_policy: {policy}\n")
+        f"XGBoost_model_policy: {policy}\n" + ("register_host_arrays: T\n" if register else ""))
 
 
 def run_driver(exe, rundir, state, out, nticks):
@@ -251,8 +251,10 @@ def two_day_case(tmp_path, small_model, exe, on_gpu):
     cfg = dict(source="ONLINE_AVG24", policy="by_name", once_per_day=True, spinup=True, run_dt=1800, oh_dt=3600,
                avg24_tick=40, ohscale=0.85)
     rundir = tmp_path / "run"
+    # on the GPU with register_host_arrays: the shell's arrays are registered at their first tick and moved by one copy
+    # launch from then on, 98 heartbeats long (the emulation below does not know the key)
     write_rundir(rundir, model_pattern=str(tmp_path / "oh_M%m2.model"), ref_time="003000", beg="20240131 000000",
-                 exports=[e for e, _ in EXPORTS], **cfg)
+                 exports=[e for e, _ in EXPORTS], register=on_gpu, **cfg)
     state, out = tmp_path / "state.bin", tmp_path / "out.bin"
     write_state_file(state, grid, imports, lats, lons)
     nticks = 98
