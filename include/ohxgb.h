@@ -286,7 +286,8 @@ int OHXBoosterKernelSymbol(BoosterHandle handle, bst_ulong ncol, const char** ou
  * OHX_UNIQUE_ID_BYTES bytes by whatever it has (MPI_Bcast in a GEOS-like host), every rank - its HIP device
  * already current - calls OHXCommInitRank.  OHXAllGatherOH only enqueues on `stream`; d_shard may be
  * d_full + row0 (in place).  Equal shards are one ncclAllGather; ragged ones - and equal ones when the
- * environment says OHX_ALLGATHER=pairs - the direct exchange of SURVEY.md §8e: one group of ncclSend / ncclRecv
+ * environment said OHX_ALLGATHER=pairs at OHXCommInitRank (read once, there; every rank must be started with the
+ * same setting) - the direct exchange of SURVEY.md §8e: one group of ncclSend / ncclRecv
  * between all pairs of ranks, every shard travelling its own xGMI link.  The communicator belongs to the HIP
  * device that was current at OHXCommInitRank: a call with another device current is refused.
  * librccl.so is loaded at the first of these calls, not linked (nor is its header needed to build). */

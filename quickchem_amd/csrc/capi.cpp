@@ -670,12 +670,17 @@ struct LevelSizeCache {
   struct Entry {
     uint64_t nrow, ncol;
     int period;      // 0 = looked and found none
+    unsigned hits;   // since the last real search
   };
   std::vector<Entry> seen;
+  // A verdict - either way - is only taken on trust fifteen times in a row; the sixteenth matrix of the shape is
+  // searched again (one read-back), so that one odd matrix - shuffled rows, a constant first column - cannot decide
+  // how every later matrix of its shape is tiled for the life of the process.
   bool find(uint64_t nrow, uint64_t ncol, int* period) {
     std::lock_guard<std::mutex> g(mu);
-    for (const Entry& e : seen)
+    for (Entry& e : seen)
       if (e.nrow == nrow && e.ncol == ncol) {
+        if (++e.hits >= 16) return false;
         *period = e.period;
         return true;
       }
@@ -686,10 +691,11 @@ struct LevelSizeCache {
     for (Entry& e : seen)
       if (e.nrow == nrow && e.ncol == ncol) {
         e.period = period;
+        e.hits = 0;
         return;
       }
     if (seen.size() >= 64) seen.erase(seen.begin());
-    seen.push_back({nrow, ncol, period});
+    seen.push_back({nrow, ncol, period, 0u});
   }
 };
 LevelSizeCache g_level_sizes;
@@ -797,7 +803,11 @@ bool defer_prepare(BoosterObj& b, uint64_t nrow, LaunchTuning& tune) {
     b.defer_pending = false;
     b.defer_too_many = (uint64_t)b.h_defer_count.p[0] * 50u > b.defer_last_nrow;        // more than 2 % of the rows
   }
+  const uint32_t* before = b.d_defer.p;
   b.d_defer.ensure((size_t)(nrow / 32 + 1024 + 1));
+  // the launchers zero the count only when they really defer (kernels.hip launch_predict: prefetch kernel, no split
+  // ...); defer_look reads it back regardless, so a buffer fresh from hipMalloc must not hold garbage
+  if (b.d_defer.p != before) HIP_CHECK(hipMemset(b.d_defer.p, 0, sizeof(uint32_t)));
   tune.defer_buf = b.d_defer.p;
   tune.defer_words = b.d_defer.n;
   tune.defer_count_only = (b.defer_too_many && tune.defer_missing < 0) ? 1 : 0;

@@ -92,14 +92,21 @@ void nccl_check(ncclResult_t rc, const char* what) {
 struct CommObj {
   ncclComm_t comm = nullptr;
   int nranks = 0, rank = 0, device = -1;
+  // how equal shards travel: fixed when the communicator is made (OHX_ALLGATHER=pairs in THAT process's environment:
+  // every rank must be started with the same setting - a rank that enqueues ncclAllGather while its peers enqueue
+  // sends and receives hangs without a word; read once so that at least a setenv between two calls cannot split them)
+  bool pairs = false;
+  // held while a call enqueues on this communicator; OHXCommFree takes it before it destroys the communicator
+  std::mutex use;
 };
 
 std::mutex g_mu;
 std::unordered_set<const void*> g_live;
 
-// A handle is checked against the table of live communicators, never by reading the object.  The lock is held by
-// the caller for as long as the object is used (a collective is only enqueued under it): a free on another thread
-// cannot pull the communicator away from under a call.
+// A handle is checked against the table of live communicators, never by reading the object.  g_mu covers the table
+// only: a call looks its communicator up under it, takes the communicator's own mutex, and lets g_mu go BEFORE it
+// talks to RCCL - ncclGroupEnd may wait for a peer, and a process that drives several ranks from several threads must
+// not hold every other communicator's calls up meanwhile.
 CommObj* as_comm_locked(OHXCommHandle h) {
   if (h == nullptr || !g_live.count(h)) throw OhxError("communicator handle is invalid or has been freed");
   return static_cast<CommObj*>(h);
@@ -162,6 +169,7 @@ int OHXCommInitRank(const void* id, int nranks, int rank, OHXCommHandle* out) {
   auto c = new CommObj();
   c->nranks = nranks;
   c->rank = rank;
+  c->pairs = pairs_wanted();
   if (hipGetDevice(&c->device) != hipSuccess) {
     delete c;
     throw OhxError("OHXCommInitRank: no current HIP device");
@@ -189,7 +197,11 @@ int OHXCommFree(OHXCommHandle handle) {
     c = as_comm_locked(handle);
     g_live.erase(handle);
   }
-  ncclResult_t rc = rccl().CommDestroy(c->comm);
+  ncclResult_t rc;
+  {
+    std::lock_guard<std::mutex> u(c->use);          // a call that found it before the erase finishes its enqueue first
+    rc = rccl().CommDestroy(c->comm);
+  }
   delete c;
   nccl_check(rc, "ncclCommDestroy");
   COMM_API_END();
@@ -215,8 +227,10 @@ int OHXShardRows(bst_ulong nrows_total, int nranks, int rank, bst_ulong* row0, b
 int OHXAllGatherOH(OHXCommHandle handle, const float* d_shard, bst_ulong nrows_local, bst_ulong nrows_total,
                    float* d_full, void* stream) {
   COMM_API_BEGIN();
-  std::lock_guard<std::mutex> g(g_mu);
+  std::unique_lock<std::mutex> table(g_mu);
   CommObj* c = as_comm_locked(handle);
+  std::lock_guard<std::mutex> use(c->use);
+  table.unlock();
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev != c->device)
     throw OhxError("OHXAllGatherOH: the communicator was made on HIP device " + std::to_string(c->device) +
@@ -231,7 +245,7 @@ int OHXAllGatherOH(OHXCommHandle handle, const float* d_shard, bst_ulong nrows_l
   if (d_full == nullptr || (d_shard == nullptr && nrows_local != 0)) throw OhxError("OHXAllGatherOH: NULL buffer");
   hipStream_t s = static_cast<hipStream_t>(stream);
   Rccl& r = rccl();
-  if (nrows_total % (bst_ulong)c->nranks == 0 && !pairs_wanted()) {
+  if (nrows_total % (bst_ulong)c->nranks == 0 && !c->pairs) {
     // equal shards: one all-gather, straight into place (in place when d_shard already is d_full + row0)
     nccl_check(r.AllGather(d_shard, d_full, (size_t)nrows_local, ncclFloat, c->comm, s), "ncclAllGather");
   } else {

@@ -284,14 +284,17 @@ def test_native_all_gather_entry_points_on_one_rank():
     assert torch.equal(full, shard)
     # the direct exchange (every shard to every peer as one group of sends and receives): with one rank its own
     # rows are a device copy and the group is empty - the code path of ragged shards
+    # (the route is fixed when the communicator is made: a setenv between two calls cannot split the ranks)
     os.environ["OHX_ALLGATHER"] = "pairs"
     try:
-        full.zero_()
-        comm.all_gather_oh(shard.data_ptr(), n, n, full.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        assert torch.equal(full, shard)
+        pairs = capi.Communicator(capi.Communicator.unique_id(), 1, 0)
     finally:
         del os.environ["OHX_ALLGATHER"]
+    full.zero_()
+    pairs.all_gather_oh(shard.data_ptr(), n, n, full.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(full, shard)
+    pairs.free()
     assert capi.Communicator.rccl_version() >= 20000                     # ncclGetVersion of the library that was loaded
     with pytest.raises(capi.OhxError, match="holds 5 rows"):
         comm.all_gather_oh(shard.data_ptr(), 5, n, full.data_ptr())
