@@ -93,8 +93,19 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
                      bst_ulong* out_len, const float** out_result);
 
 /* xgboost c_api.h; not bound by the reference.  Understood names:
- *   "ohx_kernel"      auto (= super2) | super1 | super2 | super3 | super4 | packed1 | packed2 |
- *                     packed4 | wide : node format and trees in flight per lane
+ *   "ohx_kernel"      auto | ring | super1 | super2 | super3 | super4 | packed1 | packed2 |
+ *                     packed4 | wide : node format and trees in flight per lane.  ring: super-nodes, the records
+ *                     of a walk's first four steps resident in LDS, 16 wavefronts per block walking the same four
+ *                     trees at a time (the big batches of a 27-feature booster; everything else of such a booster
+ *                     goes the super2 way).  auto = ring for 27-feature boosters of 7 or more steps per tree
+ *                     (where it is faster: 12 % at the OH booster's 9 steps), else super2
+ *   "ohx_ring_rounds" ring kernels: tiles per wavefront and launch (default 8; 0 = one launch)
+ *   "ohx_register_host"  0 | 1, process-wide (the handle may be NULL): the host arrays handed to OHXBoosterRun1,
+ *                     OHXOHPostProcess and OHXBoosterPredictFields are registered with the GPU driver the first time
+ *                     they are seen and moved by DMA - a rank-sized block's forty arrays by ONE copy launch - from
+ *                     then on (a 48 x 24 x 72 block's Run1 tick: 0.98 -> 0.52 ms; six ranks sharing the GPU: 3.3 ->
+ *                     0.7 ms).  A CONTRACT: every array passed while this is on must stay allocated until
+ *                     OHXReleaseScratch() or the end of the process (MAPL's state arrays do).  Default 0
  *   "ohx_tree_tops"   auto | on | off : super-nodes: fetch a tree's first records with one coalesced load per
  *                     wavefront (auto = forests of 7 or more steps per tree, where it is faster)
  *   "ohx_cluster"     auto | on | off : group rows of no known order by the decisions they take at the top of

@@ -518,9 +518,26 @@ __device__ __forceinline__ float walk_super(const uint4* __restrict__ nodes, con
 
 // FMT: 0 = wide 16-byte nodes, 1 = packed 8-byte nodes, 2 = 16-byte super-nodes
 template <int FMT, int CHAINS, bool TOPS>
+__device__ __forceinline__ float walk_tile_any(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads, uint32_t t0,
+                                               uint32_t t1, const float* tile, bool wave_has_missing, const char* first,
+                                               uint32_t nfirst, float* __restrict__ leaf_out);
+
+// a wave that walks is issued before a wave that fills its tile or stores (s_setprio): depth 6 / 10 / 18: -3.2 / -2.2 /
+// -0.7 % (profiles/r04_sweeps.txt; the ring kernels, where it is worth 8 %, have their own two levels)
+template <int FMT, int CHAINS, bool TOPS>
 __device__ __forceinline__ float walk_tile(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads, uint32_t t0,
                                            uint32_t t1, const float* tile, bool wave_has_missing, const char* first,
                                            uint32_t nfirst, float* __restrict__ leaf_out = nullptr) {
+  __builtin_amdgcn_s_setprio(1);
+  const float acc = walk_tile_any<FMT, CHAINS, TOPS>(fr, heads, t0, t1, tile, wave_has_missing, first, nfirst, leaf_out);
+  __builtin_amdgcn_s_setprio(0);
+  return acc;
+}
+
+template <int FMT, int CHAINS, bool TOPS>
+__device__ __forceinline__ float walk_tile_any(const DeviceForest& fr, const SuperTreeHead* __restrict__ heads, uint32_t t0,
+                                               uint32_t t1, const float* tile, bool wave_has_missing, const char* first,
+                                               uint32_t nfirst, float* __restrict__ leaf_out) {
   float acc = fr.base_score;
   if constexpr (FMT == 1) {
     const __amdgpu_buffer_rsrc_t nodes = make_rsrc(fr.packed, fr.packed_bytes);
@@ -845,6 +862,10 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
                                                  uint32_t publish_value) {
   constexpr int CHAINS = kRingChains;
   const char* tile_b = reinterpret_cast<const char*>(tile);
+  // Issue priority (s_setprio): a wave that walks goes before a wave that fills its tile, stores, stages or spins
+  // (priority 0), and the deep steps' gathers - the walk's scarce resource - before the LDS steps: the C360 step
+  // 27.4 -> 25.3 ms, the fused fields kernel 30.4 -> 27.7 ms (profiles/r04_sweeps.txt; walk 1 / deep 2 = 3 / 2 = 3 / 1)
+  __builtin_amdgcn_s_setprio(1);
   u32x4 s[CHAINS];
   uint32_t rel[CHAINS], leafb[CHAINS];
   float xr[CHAINS];
@@ -875,6 +896,7 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & (kWave - 1)) == 0) ring_store(publish_to, publish_value);
   }
+  __builtin_amdgcn_s_setprio(2);      // the gathers of the deep steps first (see above)
   for (uint32_t step = kRingSteps; step < nsteps; ++step) {
     super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
 #pragma unroll
@@ -882,6 +904,7 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
       s[c] = __builtin_amdgcn_raw_buffer_load_b128(forest, (int)((h[c].base + rel[c]) << 4), 0, 0);
   }
   super_step<CHAINS, HAS_MISSING, true>(s, rel, leafb, tile_b);
+  __builtin_amdgcn_s_setprio(0);
 #pragma unroll
   for (int c = 0; c < CHAINS; ++c)
     if ((uint32_t)c < ntrees_here) acc += __uint_as_float(leafb[c]);
