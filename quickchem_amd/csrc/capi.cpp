@@ -443,6 +443,7 @@ BoosterObj* as_booster(BoosterHandle h) {
 // with the OH recipe's boosters (profiles/r02_sweeps.txt): 9 steps per tree (depth 18) 3.4 % faster with tops, 5 steps
 // (depth 10) 10 % slower, 3 steps (depth 6) 27 % slower.
 constexpr double kTreeTopsMinMeanSteps = 7.0;
+constexpr double kRingMinMeanSteps = 5.0;
 
 KernelKind pick_kernel(const BoosterObj& b) {
   const std::string& k = b.kernel_name;
@@ -451,9 +452,10 @@ KernelKind pick_kernel(const BoosterObj& b) {
     if (k == "super1") return KernelKind::Super1;
     if (k == "super3") return KernelKind::Super3;
     if (k == "super4") return KernelKind::Super4;
-    // deep forests walk fastest with their tree tops resident in LDS (kernels.hip, the ring kernels): 12 % on the OH
-    // booster (9 steps per tree), 3 % at 7 steps, 8 % SLOWER at 5 (profiles/r04_sweeps.txt) - same bar as the tree tops
-    if (k == "ring" || (k == "auto" && b.forest.num_feature == 27 && b.super_mean_steps >= kTreeTopsMinMeanSteps))
+    // forests of some depth walk fastest with their tree tops resident in LDS (kernels.hip, the ring kernels), against
+    // the tile kernel: 9 steps per tree (the OH booster, depth 18) -20 %, 7 steps -16 %, 6 steps -6 %, 5 steps -3 %,
+    // 4 steps +2 %, 3 steps +29 % (profiles/r04_sweeps.txt)
+    if (k == "ring" || (k == "auto" && b.forest.num_feature == 27 && b.super_mean_steps >= kRingMinMeanSteps))
       return KernelKind::Ring;
     if (k == "super2" || k == "auto") return KernelKind::Super2;
   }
@@ -1721,7 +1723,7 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]) {
   // (the ring kernels where the booster's big batches go through them: pick_kernel)
   auto walk_mode = [&](double mean_steps) {
     const bool ring = b->kernel_name == "ring" ||
-                      (b->kernel_name == "auto" && b->forest.num_feature == 27 && mean_steps >= kTreeTopsMinMeanSteps);
+                      (b->kernel_name == "auto" && b->forest.num_feature == 27 && mean_steps >= kRingMinMeanSteps);
     return ring ? 2 : (use_tree_tops(b->tune, mean_steps) ? 1 : 0);
   };
   uint64_t super_gathers = b->super_gathers[walk_mode(b->super_mean_steps)];

@@ -863,8 +863,9 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
   constexpr int CHAINS = kRingChains;
   const char* tile_b = reinterpret_cast<const char*>(tile);
   // Issue priority (s_setprio): a wave that walks goes before a wave that fills its tile, stores, stages or spins
-  // (priority 0), and the deep steps' gathers - the walk's scarce resource - before the LDS steps: the C360 step
-  // 27.4 -> 25.3 ms, the fused fields kernel 30.4 -> 27.7 ms (profiles/r04_sweeps.txt; walk 1 / deep 2 = 3 / 2 = 3 / 1)
+  // (priority 0), and the further down its trees a wave is, the sooner it is issued - first step 1, the other LDS
+  // steps 2, the deep steps' gathers (the walk's scarce resource) 3: the C360 step 27.4 -> 24.8 ms, the fused fields
+  // kernel 30.4 -> 27.3 ms (profiles/r04_sweeps.txt; walk 1 / deep 2: 25.3, deep steps from the sixth on at 3: 25.0)
   __builtin_amdgcn_s_setprio(1);
   u32x4 s[CHAINS];
   uint32_t rel[CHAINS], leafb[CHAINS];
@@ -886,6 +887,7 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
   for (int c = 0; c < CHAINS; ++c) s[c] = *(lds_u32x4_ptr)(tops + (uint32_t)c * kRingTreeBytes + (rel[c] << 4));
 #pragma unroll
   for (uint32_t step = 1; step < kRingSteps; ++step) {
+    if (step == 2) __builtin_amdgcn_s_setprio(2);
     super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) s[c] = *(lds_u32x4_ptr)(tops + (uint32_t)c * kRingTreeBytes + (rel[c] << 4));
@@ -896,7 +898,7 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & (kWave - 1)) == 0) ring_store(publish_to, publish_value);
   }
-  __builtin_amdgcn_s_setprio(2);      // the gathers of the deep steps first (see above)
+  __builtin_amdgcn_s_setprio(3);      // the gathers of the deep steps first (see above)
   for (uint32_t step = kRingSteps; step < nsteps; ++step) {
     super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
 #pragma unroll

@@ -165,7 +165,7 @@ struct LaunchTuning {
   int coop_rows = 1;  // ... fetched by the wave together where a tile is made of runs of >= 4 consecutive rows
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
   // ring kernels: tiles per wave and launch (0 = one launch for the whole batch)
-  int ring_rounds = 8;
+  int ring_rounds = 16;
   // small batches: trees split over several waves per tile (PredictArgs::leaf_buf): -1 = when the batch leaves half of
   // the chip's wave slots empty, 0 = never, n > 1 = always in n runs; needs the booster's leaf buffer
   int tree_split = -1;

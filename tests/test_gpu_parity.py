@@ -730,9 +730,12 @@ RING = {"ohx_tree_split": "off"}          # a small batch would have its trees s
 
 
 def test_ring_kernel_is_the_default_for_deep_boosters(torch_cuda, small_model, deep_model):
-    """`auto` sends a deep booster's OH-shaped batches (27 columns, >= 7 steps per tree) through predict_rows_ring_kernel
-    and a shallow booster's through the tile kernel; the library names what it launches."""
-    for image, want in ((deep_model.image, "predict_rows_ring_kernel"), (small_model.image, "predict_rows_tile_kernel<2,2,true,false>")):
+    """`auto` sends the OH-shaped batches (27 columns) of a booster of five or more steps per tree through
+    predict_rows_ring_kernel - the OH booster's depth 18 (nine steps), also depth 10 (five) - and a shallow booster's
+    (depth 6: three steps) through the tile kernel; the library names what it launches."""
+    shallow = synth.make_model(num_trees=20, max_depth=6, sample_log2=13, min_leaf=4, grid=synth.GRIDS["C12"])
+    for image, want in ((deep_model.image, "predict_rows_ring_kernel"), (small_model.image, "predict_rows_ring_kernel"),
+                        (shallow.image, "predict_rows_tile_kernel<2,2,true,false>")):
         b = capi.Booster(model_buffer=image)
         assert b.kernel_symbol(27) == want
         b.free()
