@@ -287,7 +287,40 @@ def pcie_inclusive(grid, booster, dev):
             "fused_call": {"tick_ms": min(fused[1:]) * 1e3, "gridcells_per_s": n / min(fused[1:]),
                            "first_tick_ms": fused[0] * 1e3},
             "note": "one process, one C360/8-sized block; several ranks sharing the GPU overlap each other's copies: "
-                    "profiles/r03_ranks_per_gpu.json"}
+                    "profiles/r04_ranks_per_gpu.json"}
+
+
+def run1_host(booster):
+    """What a GEOS rank pays per OH tick through the GridComp shell (never `value`): OHXBoosterRun1, the HOST form -
+    the one call quickchem_amd/fortran/oh_gridcomp.F90 makes on a Boost tick (37 import arrays in; INTERNAL OH, OH_boost
+    and NDWET out; OH_GridCompMod.F90:1444-1595) - on two rank-sized blocks whose arrays stay at their addresses from
+    tick to tick, pageable and with ohx_register_host (registered once, then moved by one copy launch).  The same for
+    P ranks sharing the GPU and for a C360/8 block: tools/ranks_per_gpu.py, profiles/r04_ranks_per_gpu*.json."""
+    from quickchem_amd import synth
+    out = {"what": "OHXBoosterRun1 host form, steady-state tick (median of 20 after 3), one process", "blocks": []}
+    for block in ((48, 24, 72), (96, 48, 72)):
+        st = synth.run1_state(block, seed=5)
+        call = booster.run1_prepare(st, dynamic_k_range=True)
+        entry = {"block": list(block), "gridcells": block[0] * block[1] * block[2],
+                 "bytes_in": int(sum(a.nbytes for k, a in call["keep"].items() if k != "sca") + sum(a.nbytes for a in call["keep"]["sca"]))}
+        ref = None
+        for mode, key in (("0", "pageable_ms"), ("1", "registered_ms")):
+            booster.set_param("ohx_register_host", mode)
+            ticks = []
+            for _ in range(23):
+                t0 = time.perf_counter()
+                r = booster.run1_call(call)
+                ticks.append(time.perf_counter() - t0)
+            entry[key] = float(np.median(ticks[3:])) * 1e3
+            if ref is None:
+                ref = r["oh"].copy()
+                entry["levels_predicted"] = int(r["k2"] - r["k1"] + 1)
+            elif not np.array_equal(ref.view(np.uint32), r["oh"].view(np.uint32)):
+                raise SystemExit("bench: OHXBoosterRun1 on registered arrays differs from the pageable run")
+        out["blocks"].append(entry)
+    booster.set_param("ohx_register_host", "0")
+    booster.lib.OHXReleaseScratch()
+    return out
 
 
 def bench_run1(args, grid, n_total, model, booster, dev, t_model):
@@ -694,9 +727,12 @@ def main():
 
     info = booster.info()
     symbol = booster.kernel_symbol(27)
-    # tiles per launch: the ring kernel takes 8 rounds of one 16-wave block per CU, the tile kernel 2 of 20 waves per CU
+    # tiles per launch: the ring kernel takes 16 rounds (ohx_ring_rounds) of one 16-wave block per CU, the tile kernel
+    # 2 (ohx_launches_per_residency) of 20 waves per CU
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    per_launch = cus * 16 * 8 if "ring" in symbol else cus * 20 * 2
+    knob = {kv.partition("=")[0]: kv.partition("=")[2] for kv in args.param}
+    rounds = int(knob.get("ohx_ring_rounds", 16)) if "ring" in symbol else int(knob.get("ohx_launches_per_residency", 2))
+    per_launch = (cus * 16 if "ring" in symbol else cus * 20) * rounds if rounds > 0 else 1 << 62
     launches_per_step = sum(-(-((hi - lo + 63) // 64) // per_launch) for lo, hi in pieces)
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total / (elapsed / args.steps)
@@ -720,9 +756,10 @@ def main():
             raise SystemExit("bench: GPU margins differ from the oracle on the first rows of the batch")
         cpu["margins_bit_identical_on_first_rows"] = n_chk
 
-    pcie = None
+    pcie = host_tick = None
     if rank == 0 and world == 1 and plain and not args.no_pcie and args.cpu_seconds > 0 and use_grid:
         pcie = pcie_inclusive(grid, booster, dev)
+        host_tick = run1_host(booster)
     if rank == 0:
         traffic, traffic_src = (None, "not the default single-GPU workload")
         if world == 1 and use_grid and plain and not args.param:
@@ -768,6 +805,7 @@ def main():
                          "gather_issue": gather_issue(info, n_local, kernel_s, dev, 7 if (use_grid or args.consecutive or args.infer_grid or args.no_grid) and not args.shuffle else 9)},
             "cpu_baseline": cpu,
             "pcie_inclusive": pcie,
+            "run1_host": host_tick,
         }
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:

@@ -143,6 +143,42 @@ __device__ __forceinline__ bool fill_tile_rows(float* __restrict__ tile, const f
   return any_nan;
 }
 
+// One lane's row of the fused path into its column of the wave's tile: field after field (the reference's gather,
+// OH_GridCompMod.F90:308-345, PL / 100 at :314), `missing` -> NaN.  The fields come one after the other, each load
+// waited for before the next is issued: issuing the 27 loads together is SLOWER (35.2 against 33.6 ms per C360 step) - a
+// burst of 27 four-byte gathers from one wave stands in front of the other waves' node gathers at the texture
+// addresser (profiles/r03_sweeps.txt).  Returns whether the lane's row holds a missing value.
+__device__ __forceinline__ bool fill_tile_fields(const FieldsArgs& a, float* __restrict__ tile, uint32_t nfeat, uint64_t m,
+                                                 uint64_t col, uint64_t slab, bool valid, bool missing_is_nan) {
+  const float qnan = __builtin_nanf("");
+  bool lane_nan = false, any_inf = false;
+  for (uint32_t f = 0; f < nfeat; ++f) {
+    float x = qnan;
+    if (valid && f < a.nfield) {
+      const float* src = a.field[f];
+      x = ((a.is2d_mask >> f) & 1u) ? src[col] : __builtin_nontemporal_load(src + slab + m);
+      if (f == a.pl_feature) x = x / 100.0f;
+      any_inf |= is_inf(x);
+      if (!missing_is_nan && x == a.missing) x = qnan;
+    }
+    if (!valid) x = 0.0f;
+    lane_nan |= (x != x);
+    tile[f * kWave] = x;
+  }
+  if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
+  return lane_nan;
+}
+
+// what the fused path stores for a gridcell: the margin (optional) and 10**margin * OHscale (:369, :1569)
+__device__ __forceinline__ void store_oh(const FieldsArgs& a, float* __restrict__ out, float* __restrict__ margin_out,
+                                         uint64_t slab_out, uint64_t m, float acc) {
+  if (margin_out) margin_out[m] = acc;
+  float oh = acc;
+  if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);      // 10.0**x rounded once from double: agrees with a correctly rounded powf
+  oh = oh * a.scale;
+  out[slab_out + m] = oh;
+}
+
 // The OH shape (27 columns, 27 features): a row held in registers, so the NEXT tile's rows can
 // be in flight from HBM while the current tile is walked (the walk needs no registers of it).
 struct Row27 {
@@ -1073,7 +1109,6 @@ __global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4)))
   const uint64_t first_tile = a.tile_begin + (uint64_t)block * kRingWaves;
   if (first_tile >= a.tile_end) return;
   const uint32_t rounds = (uint32_t)((a.tile_end - first_tile + nwaves - 1) / nwaves);
-  const float qnan = __builtin_nanf("");
   TopRing rg;
   ring_begin(rg, reinterpret_cast<char*>(lds + (size_t)kRingWaves * 27 * kWave), fr, heads, a.tree_begin, a.tree_end, rounds);
   uint64_t tile_id = a.tile_begin + wave_id;
@@ -1082,25 +1117,7 @@ __global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4)))
     uint64_t m = 0;
     if (tile_id < a.tile_end) m = tile_row(a.shape, tile_id, lane, nrow, &valid);
     const bool live = __any(valid);
-    bool lane_nan = false, any_inf = false;
-    if (live) {
-      const uint64_t col = valid ? m % plane : 0;
-      // one field after the other, as in predict_fields_kernel (a burst of 27 loads measured slower)
-      for (uint32_t f = 0; f < 27u; ++f) {
-        float x = qnan;
-        if (valid && f < a.nfield) {
-          const float* src = a.field[f];
-          x = ((a.is2d_mask >> f) & 1u) ? src[col] : __builtin_nontemporal_load(src + slab + m);
-          if (f == a.pl_feature) x = x / 100.0f;
-          any_inf |= is_inf(x);
-          if (!missing_is_nan && x == a.missing) x = qnan;
-        }
-        if (!valid) x = 0.0f;
-        lane_nan |= (x != x);
-        tile[f * kWave] = x;
-      }
-      if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
-    }
+    const bool lane_nan = live && fill_tile_fields(a, tile, 27u, m, valid ? m % plane : 0, slab, valid, missing_is_nan);
     bool wave_nan = __any(lane_nan);
     bool keep = valid;
     if (wave_nan && a.defer_count != nullptr && a.defer_cap == 0u) {
@@ -1122,13 +1139,7 @@ __global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4)))
       }
     }
     const float acc = ring_walk_tile(rg, fr.base_score, tile, live, wave_nan, lane, wave);
-    if (keep && !rg.gave_up) {
-      if (margin_out) margin_out[m] = acc;
-      float oh = acc;
-      if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);      // rounded once from double, as predict_fields_kernel
-      oh = oh * a.scale;
-      out[slab_out + m] = oh;
-    }
+    if (keep && !rg.gave_up) store_oh(a, out, margin_out, slab_out, m, acc);
   }
   if (rg.gave_up && a.flags) atomicOr(a.flags, kFlagRingTimeout);
 }
@@ -1208,7 +1219,27 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
   if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const uint64_t wave_id = (uint64_t)block * kWavesPerBlock + wave;
   const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
-  const float qnan = __builtin_nanf("");
+  if constexpr (FMT == 2) {
+    if (a.leaf_buf != nullptr) {
+      // a small slab (a rank's block): work item = (run of trees, tile) as in predict_rows_tile_kernel; every item
+      // fills its tile itself and writes its trees' leaves, combine_leaves_fields_kernel sums and stores them
+      const uint32_t ntree = a.tree_end - a.tree_begin;
+      const uint32_t per = ((ntree + a.tree_split - 1) / a.tree_split + (CHAINS - 1)) / CHAINS * CHAINS;
+      const uint64_t ntiles = a.tile_end - a.tile_begin, items = ntiles * a.tree_split;
+      for (uint64_t item = wave_id; item < items; item += nwaves) {
+        const uint64_t tile_id = a.tile_begin + item % ntiles;
+        const uint32_t t0 = a.tree_begin + (uint32_t)(item / ntiles) * per;
+        const uint32_t t1 = t0 + per < a.tree_end ? t0 + per : a.tree_end;
+        bool valid;
+        const uint64_t m = tile_row(a.shape, tile_id, lane, nrow, &valid);
+        if (!__any(valid) || t0 >= t1) continue;
+        const bool lane_nan = fill_tile_fields(a, tile, fr.num_feature, m, valid ? m % plane : 0, slab, valid, missing_is_nan);
+        float* leaves = a.leaf_buf + ((size_t)(tile_id - a.tile_begin) * ntree - a.tree_begin) * kWave + lane;
+        (void)walk_tile<FMT, CHAINS, TOPS>(fr, heads, t0, t1, tile, __any(lane_nan), first, nfirst, leaves);
+      }
+      return;
+    }
+  }
   // the second launch of a deferred-rows call (PredictArgs::defer_list): the rows of the list, as many as the first filled
   uint64_t slots = 0, tile_end = a.tile_end;
   if (a.perm != nullptr) {
@@ -1230,26 +1261,7 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
       m = tile_row(a.shape, tile_id, lane, nrow, &valid);
     }
     if (!__any(valid)) continue;                       // a brick without a row of the slab, a tile of empty slots
-    const uint64_t col = valid ? m % plane : 0;
-    bool lane_nan = false, any_inf = false;
-    // The fields come one after the other, each load waited for before the next is issued.  Issuing the OH gather's
-    // 27 loads together (a compile-time unrolled fill) is SLOWER: 35.2 against 33.6 ms per C360 step - a burst of 27
-    // four-byte gathers from one wave stands in front of the other waves' node gathers at the texture addresser,
-    // which a walk that is bound there feels more than this wave feels its own latency (profiles/r03_sweeps.txt).
-    for (uint32_t f = 0; f < fr.num_feature; ++f) {
-      float x = qnan;
-      if (valid && f < a.nfield) {
-        const float* src = a.field[f];
-        x = ((a.is2d_mask >> f) & 1u) ? src[col] : __builtin_nontemporal_load(src + slab + m);
-        if (f == a.pl_feature) x = x / 100.0f;
-        any_inf |= is_inf(x);
-        if (!missing_is_nan && x == a.missing) x = qnan;
-      }
-      if (!valid) x = 0.0f;
-      lane_nan |= (x != x);
-      tile[f * kWave] = x;
-    }
-    if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
+    const bool lane_nan = fill_tile_fields(a, tile, fr.num_feature, m, valid ? m % plane : 0, slab, valid, missing_is_nan);
     bool wave_nan = __any(lane_nan);
     bool keep = valid;
     // rows with missing values leave for the second launch, as in the rows kernel (every lane filled its own row here)
@@ -1272,14 +1284,28 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
       }
     }
     const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
-    if (keep) {
-      if (margin_out) margin_out[m] = acc;
-      float oh = acc;
-      // 10.0**x rounded once from double: agrees with a correctly rounded powf
-      if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);
-      oh = oh * a.scale;
-      out[slab_out + m] = oh;
-    }
+    if (keep) store_oh(a, out, margin_out, slab_out, m, acc);
+  }
+}
+
+// The second launch of a small slab (FieldsArgs::leaf_buf): margin = ((base + leaf_0) + leaf_1) + ..., then 10** and OHscale
+__global__ __launch_bounds__(kBlock) void combine_leaves_fields_kernel(FieldsArgs a, float base_score, float* __restrict__ out,
+                                                                        float* __restrict__ margin_out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t nrow = plane * (uint64_t)(a.k2 - a.k1 + 1);
+  const uint64_t slab_out = plane * (uint64_t)(a.k1 - a.out_k0);
+  const uint64_t ntiles = a.tile_end - a.tile_begin, nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+  const uint32_t ntree = a.tree_end - a.tree_begin;
+  for (uint64_t w = (uint64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave; w < ntiles; w += nwaves) {
+    bool valid;
+    const uint64_t m = tile_row(a.shape, a.tile_begin + w, lane, nrow, &valid);
+    if (!__any(valid)) continue;
+    const float* leaves = a.leaf_buf + (size_t)w * ntree * kWave + lane;
+    float acc = base_score;
+#pragma unroll 4
+    for (uint32_t t = 0; t < ntree; ++t) acc += leaves[(size_t)t * kWave];
+    if (valid) store_oh(a, out, margin_out, slab_out, m, acc);
   }
 }
 
@@ -2037,6 +2063,25 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
   return hipGetLastError();
 }
 
+// A small slab: the trees in `split` runs, a wave per (run, tile), then the launch that sums the leaves in tree order
+template <class K>
+hipError_t launch_fields_split(K kernel, size_t lds, const DeviceForest& fr, FieldsArgs a, int num_cus, hipStream_t stream,
+                               const LaunchTuning& tune, uint32_t split) {
+  hipError_t e = ensure_lds(kernel, lds);
+  if (e != hipSuccess) return e;
+  a.xcd_remap = tune.xcd_remap;
+  a.tile_begin = 0;
+  a.tile_end = a.shape.ntiles((uint64_t)a.im * a.jm * (uint64_t)(a.k2 - a.k1 + 1));
+  a.leaf_buf = tune.leaf_buf;
+  a.tree_split = split;
+  const int grid = tile_grid(kernel, lds, a.tile_end * split, num_cus);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, fr, a, fr.super_heads, a.out, a.margin_out);
+  const uint64_t blocks = (a.tile_end + kWavesPerBlock - 1) / kWavesPerBlock;
+  hipLaunchKernelGGL(combine_leaves_fields_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(kBlock), 0, stream, a,
+                     fr.base_score, a.out, a.margin_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const FieldsArgs& a, int num_cus,
                                  hipStream_t stream, const LaunchTuning& tune) {
   if (a.k2 < a.k1 || a.im <= 0 || a.jm <= 0) return hipSuccess;
@@ -2054,6 +2099,29 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   if (fr.tree_tops) OHX_LAUNCH_FIELDS_T(FMT, CH, true); \
   OHX_LAUNCH_FIELDS_T(FMT, CH, false)
   if (use_wide) OHX_LAUNCH_FIELDS_T(0, 1, false);
+  // A small slab - a GEOS rank's block - leaves most of the chip's wave slots empty and takes as long as one tile's walk
+  // of ALL trees: its trees are cut into runs walked by different waves, as launch_predict does for small row batches
+  if (is_super && tune.tree_split != 0 && tune.leaf_buf != nullptr && a.tree_end - a.tree_begin >= 8) {
+    FieldsArgs probe = a;
+    if (tune.brick_li < 0) probe.shape.set_grid_auto((uint32_t)a.im, (uint32_t)a.jm, 0, nrow);
+    else if (tune.brick_li + tune.brick_lj + tune.brick_lk == 6)
+      probe.shape.set_grid((uint32_t)a.im, (uint32_t)a.jm, 0, nrow, (uint32_t)tune.brick_li, (uint32_t)tune.brick_lj,
+                           (uint32_t)tune.brick_lk);
+    probe.shape.k_fastest = (uint32_t)tune.brick_k_fastest;
+    const uint64_t ntiles = probe.shape.ntiles(nrow);
+    const uint64_t live = probe.shape.im != 0 && probe.shape.live_tiles() < ntiles ? probe.shape.live_tiles() : ntiles;
+    const uint64_t slots = (uint64_t)num_cus * 20u;
+    const uint32_t ntree = a.tree_end - a.tree_begin;
+    uint64_t want = tune.tree_split > 1 ? (uint64_t)tune.tree_split : (live * 2 <= slots ? slots / (live ? live : 1) : 0);
+    if (want > 10) want = 10;
+    if (want * 4 > ntree) want = ntree / 4;
+    if (want >= 2 && ntiles < 0xFFFFFFFFull && ntiles * ntree * kWave <= tune.leaf_words) {
+      if (kind == KernelKind::Super1) return launch_fields_split(predict_fields_kernel<2, 1, false>, lds, fr, probe, num_cus, stream, tune, (uint32_t)want);
+      if (kind == KernelKind::Super4) return launch_fields_split(predict_fields_kernel<2, 4, false>, lds, fr, probe, num_cus, stream, tune, (uint32_t)want);
+      if (fr.tree_tops) return launch_fields_split(predict_fields_kernel<2, 2, true>, lds, fr, probe, num_cus, stream, tune, (uint32_t)want);
+      return launch_fields_split(predict_fields_kernel<2, 2, false>, lds, fr, probe, num_cus, stream, tune, (uint32_t)want);
+    }
+  }
   // the ring kernel for slabs that fill the chip at least twice; smaller ones (a rank-sized block) the super2 way:
   // a block of the ring kernel is 16 tiles that wait for each other's trees
   if (kind == KernelKind::Ring && fr.num_feature == 27 && nrow >= (uint64_t)num_cus * kRingWaves * kWave * 2u)

@@ -220,6 +220,9 @@ struct FieldsArgs {
   const uint32_t* perm = nullptr;        // second launch: lane l of tile t takes slab row perm[64 t + l]
   const uint32_t* perm_count = nullptr;
   uint32_t perm_slots = 0;
+  // small slabs: the trees split over waves, as PredictArgs::leaf_buf / tree_split
+  float* leaf_buf = nullptr;
+  uint32_t tree_split = 1;
 };
 
 // OH Run1's feature engineering and post-processing (include/ohxgb.h part 3), device pointers.

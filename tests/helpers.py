@@ -135,34 +135,9 @@ def load_hand_cases():
 
 
 def run1_state(grid, seed=17):
-    """A synthetic OH import state for OHXBoosterRun1: physically plausible magnitudes, arbitrary values."""
-    im, jm, km = grid
-    rng = np.random.default_rng(seed)
-    f32 = np.float32
-
-    def u(lo, hi, shape):
-        return (lo + (hi - lo) * rng.random(shape)).astype(f32)
-    ps = u(6.0e4, 1.04e5, (im, jm))
-    sig = (np.arange(km + 1, dtype=f32) / f32(km)) ** 2
-    ple = (f32(1.0) + (ps[:, :, None] - f32(1.0)) * sig[None, None, :]).astype(f32)         # Pa, edges 0..km
-    zle = (f32(8.0e4) * (f32(1.0) - sig[None, None, :]) * u(0.9, 1.1, (im, jm))[:, :, None]).astype(f32)
-    vol, plane = (im, jm, km), (im, jm)
-    cloudy = rng.random(vol) < 0.25
-    st = {
-        "ple_mod": ple, "ple_bst": (ple * u(0.98, 1.02, (im, jm))[:, :, None]).astype(f32), "zle_bst": zle,
-        "t_mod": u(190, 310, vol), "q_mod": u(1e-7, 2e-2, vol), "tropp_mod": u(9.0e3, 3.0e4, plane),
-        "tauclw": np.where(cloudy, u(0, 8, vol), 0).astype(f32), "taucli": np.where(~cloudy & (rng.random(vol) < 0.2), u(0, 3, vol), 0).astype(f32),
-        "scacoef": [u(0, 5e-6, vol) for _ in range(7)],
-        "gmito3": u(250, 450, plane), "gmitto3": u(20, 60, plane),
-        "lat_deg": u(-90, 90, plane), "t_bst": u(190, 310, vol), "cloud": np.clip(u(-0.5, 1.0, vol), 0, 1).astype(f32),
-        "qv": u(1e-7, 2e-2, vol), "albuv": u(0.02, 0.9, plane), "sza": u(0, 113, plane),
-        "default_oh": u(1e-15, 5e-13, vol),
-    }
-    for name, lo in (("no2", 1e-12), ("o3", 1e-8), ("ch4", 1.6e-6), ("co", 2e-8), ("isop", 1e-14), ("acet", 1e-11),
-                     ("c2h6", 1e-11), ("c3h8", 1e-12), ("prpe", 1e-13), ("alk4", 1e-12), ("mp", 1e-11), ("h2o2", 1e-11),
-                     ("ch2o", 1e-12)):
-        st[name] = (f32(lo) * np.exp2(u(0, 8, vol))).astype(f32)
-    return st
+    """A synthetic OH import state for OHXBoosterRun1 (quickchem_amd.synth.run1_state)."""
+    from quickchem_amd import synth
+    return synth.run1_state(grid, seed)
 
 
 RUN1_DRIVER_HIP = os.path.join(ROOT, "quickchem_amd", "lib", "oh_run1_driver_hip")

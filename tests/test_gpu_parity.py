@@ -845,3 +845,32 @@ def test_ring_fused_fields_vs_oracle(torch_cuda, deep_model, dynamic):
         assert np.array_equal(helpers.bits(margins[0]), helpers.bits(margin_ref)), defer
         assert np.all(oh[:, :, :k1 - 1] == 0)
         assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2
+
+
+@pytest.mark.parametrize("kernel", ["super1", "super2", "super4", "ring", "auto"])
+def test_fused_fields_small_slab_with_its_trees_split_over_waves(torch_cuda, deep_model, kernel):
+    """The fused call on a slab that leaves the chip mostly empty (a GEOS rank's block): its trees are cut into runs
+    walked by different waves and summed in tree order by a second launch, as small row batches are - whatever the number
+    of runs, with -999.0 and NaN in the fields; margins bit for bit, OH_ML within 2 ulp (10**x), levels above the slab
+    untouched."""
+    grid = (24, 12, 72)
+    pl, tropp, fields = helpers.synth_state(grid)
+    rng = np.random.default_rng(29)
+    fields = [f.copy() for f in fields]
+    for f in fields[2:]:
+        mask = rng.random(f.shape) < 1e-3
+        f[mask] = np.where(rng.random(int(mask.sum())) < 0.5, np.float32(synth.XX_MISS), np.float32(np.nan))
+    oh_ref, margin_ref, k1, k2 = helpers.oracle_predict_oh(deep_model.image, pl, tropp, fields, True)
+    for split in ("off", "auto", "2", "3", "7", "10"):
+        p = oh_predict.OHPredictor()
+        p.xx_bst = capi.Booster(model_buffer=deep_model.image)
+        p.xx_bst.set_param("ohx_kernel", kernel)
+        p.xx_bst.set_param("ohx_tree_split", split)
+        p.first_time = False
+        oh = np.zeros(grid, dtype=np.float32)
+        margins = []
+        assert p.predict_OH_with_XGB("unused", *grid, True, 4000.0, pl, tropp, oh_predict.OHBoostInputData(fields), oh,
+                                     mode="fused", margin_out=margins) == 0
+        assert np.array_equal(helpers.bits(margins[0]), helpers.bits(margin_ref)), split
+        assert np.all(oh[:, :, :k1 - 1] == 0)
+        assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2, split

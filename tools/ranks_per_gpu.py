@@ -90,10 +90,9 @@ def child(args):
         ticks["fused"].append(time.perf_counter() - t0)
         ends["fused"].append(time.time())
     t_fused1 = time.time()
-    # OH Run1 through its host form, on the rank's block: a synthetic import state (tests/helpers.run1_state: plausible
+    # OH Run1 through its host form, on the rank's block: a synthetic import state (quickchem_amd.synth.run1_state: plausible
     # magnitudes), the arrays at fixed addresses from tick to tick as MAPL's state pointers are
-    from tests import helpers as test_helpers
-    st = test_helpers.run1_state(sub, seed=17 + args.rank)
+    st = synth.run1_state(sub, seed=17 + args.rank)
     call = b.run1_prepare(st, dynamic_k_range=True, want_boost=True, want_ndwet=True)
     windows = {"reference": [t_ref0, t_ref1], "fused": [t_ref1, t_fused1]}
     first_oh = None
