@@ -634,7 +634,9 @@ def main():
     use_grid = not (args.no_grid or args.shuffle or args.infer_grid or args.consecutive)
     # pieces are whole levels when the shard is (bricks then have no idle lanes), else whole launches
     granule = plane if (use_grid and row0 % plane == 0 and n_local % plane == 0) else 64 * 256 * 20 * 2
-    round_rows = torch.cuda.get_device_properties(dev).multi_processor_count * 20 * 64   # one residency of the chip
+    # one residency of the chip: 20 waves per CU for the tile kernels, one 16-wave block per CU for the ring kernels
+    waves_per_cu = 16 if "ring" in booster.kernel_symbol(27) else 20
+    round_rows = torch.cuda.get_device_properties(dev).multi_processor_count * waves_per_cu * 64
     pieces = shard.plan_pieces(n_local, args.gather_chunks if (gather and even) else 1, granule, round_rows)
     dmats = [capi.DMatrix(device_ptr=rows.data_ptr() + lo * synth.NFEAT * 4, nrow=hi - lo, ncol=synth.NFEAT,
                           missing=synth.XX_MISS) for lo, hi in pieces]
