@@ -76,6 +76,8 @@ def child(args):
         t0 = time.perf_counter()
         if b is None:                                      # first_time (:242-271): create + load, from the file
             b = capi.Booster(args.model)
+            for kv in args.param:
+                b.set_param(*kv.split("=", 1))
         d = capi.DMatrix(rows, missing=synth.XX_MISS)
         p = b.predict(d)
         d.free()
@@ -134,7 +136,7 @@ def parent(args):
     model = synth.make_model()
     path = os.path.join(tmp, "oh.model")
     open(path, "wb").write(bytes(model.image))
-    result = {"grid": args.grid, "block": args.block, "model_file_bytes": os.path.getsize(path), "ticks": args.ticks,
+    result = {"grid": args.grid, "block": args.block, "params": args.param, "model_file_bytes": os.path.getsize(path), "ticks": args.ticks,
               "note": "P processes on one GPU, each a rank owning C360/(8P) gridcells in pageable host arrays; "
                       "aggregate = the gridcells of the ticks that end inside the interval in which every rank is "
                       "past its first tick and none has finished, over that interval",
@@ -148,6 +150,8 @@ def parent(args):
                    "--grid", args.grid, "--ticks", str(args.ticks), "--start-at", repr(start_at), "--hold-until", repr(hold_until)]
             if args.block:
                 cmd += ["--block", "%d,%d" % tuple(args.block)]
+            for kv in args.param:
+                cmd += ["--param", kv]
             procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         ranks = []
         for p in procs:                                     # children hold their memory until killed below
@@ -192,6 +196,7 @@ def main():
     ap.add_argument("--ticks", type=int, default=100)
     ap.add_argument("--prep-s", type=float, default=60.0, help="time the ranks get to build their host arrays before the common start")
     ap.add_argument("--block", default="", help="im,jm: every rank owns an (im, jm, 72) block of its own instead of C360/(8P)")
+    ap.add_argument("--param", action="append", default=[], help="XGBoosterSetParam name=value for every rank's booster (repeatable)")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--nranks", type=int, default=1)
