@@ -802,9 +802,19 @@ const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a,
 // A small batch or slab: room for the leaves of its trees, so that they can be walked by several waves per tile
 // (kernels.hpp PredictArgs::leaf_buf; only batches that can qualify: their tiles fill at most half of the chip's 20
 // waves per CU).
-void leaf_room(BoosterObj& b, uint64_t nrow, uint32_t ntree, LaunchTuning& tune) {
-  if (tune.tree_split == 0 || !b.super_ok || nrow > (uint64_t)b.dev.num_cus * 10u * 64u + 4096u) return;
-  const size_t tiles = (size_t)(nrow / 32 + 256);                    // bricks of which at least half hold rows
+// `im`, `jm`, `row0`: the grid the rows come from (0 = unknown): the buffer is sized for the tiles the launcher will
+// really make of them - bricks over the rows' levels, or 64 consecutive rows where bricks would be mostly empty -
+// not for a bound (a 48 x 24 x 72 rank block took 73 MB per booster; now 24 MB).
+void leaf_room(BoosterObj& b, uint64_t nrow, uint32_t ntree, LaunchTuning& tune, int im, int jm, uint64_t row0) {
+  if (tune.tree_split == 0 || !b.super_ok || nrow == 0 || nrow > (uint64_t)b.dev.num_cus * 10u * 64u + 4096u) return;
+  size_t tiles = (size_t)((nrow + 63) / 64);
+  if (im > 0 && jm > 0) {
+    TileShape probe;
+    if (tune.brick_li < 0) probe.set_grid_auto((uint32_t)im, (uint32_t)jm, row0, nrow);
+    else if (tune.brick_li + tune.brick_lj + tune.brick_lk == 6)
+      probe.set_grid((uint32_t)im, (uint32_t)jm, row0, nrow, (uint32_t)tune.brick_li, (uint32_t)tune.brick_lj, (uint32_t)tune.brick_lk);
+    if (probe.im != 0 && probe.ntiles(nrow) > tiles) tiles = (size_t)probe.ntiles(nrow);
+  }
   b.d_leaves.ensure(tiles * 64 * (size_t)ntree);
   tune.leaf_buf = b.d_leaves.p;
   tune.leaf_words = b.d_leaves.n;
@@ -866,7 +876,7 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
   tune.grid_jm = d.grid_jm;
   tune.grid_row0 = d.grid_row0;
   a.perm = cluster_rows(b, d, a, pred_leaf, kind, stream);
-  if (!pred_leaf && a.perm == nullptr) leaf_room(b, d.nrow, a.tree_end - a.tree_begin, tune);
+  if (!pred_leaf && a.perm == nullptr) leaf_room(b, d.nrow, a.tree_end - a.tree_begin, tune, tune.grid_im, tune.grid_jm, tune.grid_row0);
   // rows with missing values leave for a second, small launch instead of slowing their whole wave down (big batches)
   const bool deferring = a.perm == nullptr && !pred_leaf && d.ncol == 27 && defer_prepare(b, d.nrow, tune);
   HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, tune));
@@ -1318,7 +1328,7 @@ int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fie
   if (a.k2 >= a.k1) {
     const uint64_t nrow = (uint64_t)im * (uint64_t)jm * (uint64_t)(a.k2 - a.k1 + 1);
     LaunchTuning tune = b->tune;
-    leaf_room(*b, nrow, a.tree_end - a.tree_begin, tune);
+    leaf_room(*b, nrow, a.tree_end - a.tree_begin, tune, im, jm, 0);
     const bool deferring = nfield == 27 && defer_prepare(*b, nrow, tune);
     HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus,
                                     static_cast<hipStream_t>(stream), tune));
@@ -1394,7 +1404,7 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
     piece.margin_out = margin_base ? const_cast<float*>(margin_base) + plane * l0 : nullptr;
     LaunchTuning tune = b->tune;
     const uint64_t piece_rows = plane * (l1 - l0);
-    leaf_room(*b, piece_rows, piece.tree_end - piece.tree_begin, tune);
+    leaf_room(*b, piece_rows, piece.tree_end - piece.tree_begin, tune, im, jm, 0);
     const bool deferring = nfield == 27 && defer_prepare(*b, piece_rows, tune);
     HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), piece, b->dev.num_cus, b->s_exec, tune));
     if (deferring) defer_look(*b, piece_rows, b->s_exec);
@@ -1487,7 +1497,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
     if (pick_kernel(b) == KernelKind::Wide) ensure_wide(b);
     const uint64_t slab_rows = plane * (uint64_t)(k2 - k1 + 1);
     LaunchTuning tune = b.tune;
-    leaf_room(b, slab_rows, fa.tree_end - fa.tree_begin, tune);
+    leaf_room(b, slab_rows, fa.tree_end - fa.tree_begin, tune, r.im, r.jm, 0);
     const bool deferring = defer_prepare(b, slab_rows, tune);
     HIP_CHECK(launch_predict_fields(pick_kernel(b), device_forest(b), fa, b.dev.num_cus, stream, tune));
     if (deferring) defer_look(b, slab_rows, stream);

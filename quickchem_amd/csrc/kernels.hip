@@ -1963,7 +1963,7 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
   // the ring kernel takes the OH shape with the next rows in flight (a big batch); everything else of a booster
   // that asked for it - small batches with their trees split over waves, other column counts, the second launch of
   // the deferred rows - goes the super2 way
-  if (kind == KernelKind::Ring && pf && !split) {
+  if (kind == KernelKind::Ring && pf && !split && a.tree_end > a.tree_begin) {
     hipError_t e_ = launch_rows_ring(fr, a, num_cus, stream, tune);
     if (e_ == hipSuccess && listing)
       e_ = launch_deferred(predict_rows_tile_kernel<2, 2, false, true>, lds, fr, a, num_cus, stream);
@@ -2133,7 +2133,8 @@ hipError_t launch_predict_fields(KernelKind kind, const DeviceForest& fr, const 
   }
   // the ring kernel for slabs that fill the chip at least twice; smaller ones (a rank-sized block) the super2 way:
   // a block of the ring kernel is 16 tiles that wait for each other's trees
-  if (kind == KernelKind::Ring && fr.num_feature == 27 && nrow >= (uint64_t)num_cus * kRingWaves * kWave * 2u)
+  if (kind == KernelKind::Ring && fr.num_feature == 27 && a.tree_end > a.tree_begin &&
+      nrow >= (uint64_t)num_cus * kRingWaves * kWave * 2u)
     return launch_fields_tiled(predict_fields_ring_kernel, kRingLdsBytes, fr, a, nrow, num_cus, stream, tune, kRingWaves,
                                tune.ring_rounds);
   switch (kind) {

@@ -41,7 +41,7 @@ def test_full_size_properties(full_model, gridname, shard):
     synth.rows_device(grid, row0, n, rows)
     synth.inject_missing_device(rows, 100)                     # 1e-4 of the entries: -999.0 or NaN
     booster = capi.Booster(model_buffer=full_model.image)
-    a = _predict_dev(torch, booster, rows, "auto")             # the shipped default (super-nodes, 2 chains)
+    a = _predict_dev(torch, booster, rows, "auto")             # the shipped default (the ring kernel for this booster)
     b = _predict_dev(torch, booster, rows, "wide")             # different node format, no LDS tile, 1 chain
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     for other in ("packed1", "packed4", "super1", "super4"):
