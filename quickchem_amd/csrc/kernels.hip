@@ -1847,13 +1847,19 @@ hipError_t launch_rows_ring(const DeviceForest& fr, PredictArgs a, int num_cus, 
     }
   }
   const uint64_t per_launch = tune.ring_rounds <= 0 ? ntiles : grid * kRingWaves * (uint64_t)tune.ring_rounds;
+  TrainCursor train(stream, tune);
   for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
     a.tile_begin = t0;
     a.tile_end = t0 + per_launch < ntiles ? t0 + per_launch : ntiles;
     const uint64_t blocks = (a.tile_end - a.tile_begin + kRingWaves - 1) / kRingWaves;
+    hipStream_t s;
+    e = train.next(&s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(predict_rows_ring_kernel, dim3((unsigned)(blocks < grid ? blocks : grid)), dim3(kRingBlock),
-                       kRingLdsBytes, stream, fr, a, fr.super_heads, a.out);
+                       kRingLdsBytes, s, fr, a, fr.super_heads, a.out);
   }
+  e = train.meet();
+  if (e != hipSuccess) return e;
   return hipGetLastError();
 }
 
