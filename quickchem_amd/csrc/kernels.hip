@@ -904,13 +904,15 @@ template <bool HAS_MISSING>
 __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingChains], uint32_t ntrees_here,
                                                  __amdgpu_buffer_rsrc_t forest, const float* __restrict__ tile,
                                                  lds_cptr tops, float acc, lds_u32_ptr publish_to,
-                                                 uint32_t publish_value) {
+                                                 uint32_t publish_value, bool ahead) {
   constexpr int CHAINS = kRingChains;
   const char* tile_b = reinterpret_cast<const char*>(tile);
   // Issue priority (s_setprio): a wave that walks goes before a wave that fills its tile, stores, stages or spins
   // (priority 0), and the further down its trees a wave is, the sooner it is issued - first step 1, the other LDS
   // steps 2, the deep steps' gathers (the walk's scarce resource) 3: the C360 step 27.4 -> 24.8 ms, the fused fields
-  // kernel 30.4 -> 27.3 ms (profiles/r04_sweeps.txt; walk 1 / deep 2: 25.3, deep steps from the sixth on at 3: 25.0)
+  // kernel 30.4 -> 27.3 ms (profiles/r04_sweeps.txt; walk 1 / deep 2: 25.3, deep steps from the sixth on at 3: 25.0).
+  // `ahead`: this wave was first at the group (it staged the next one) - it walks one level lower (1 / 1 / 2), so that
+  // the waves behind it, which every wave of the block ends up waiting for, catch up: 24.7 -> 24.4 ms
   __builtin_amdgcn_s_setprio(1);
   u32x4 s[CHAINS];
   uint32_t rel[CHAINS], leafb[CHAINS];
@@ -932,7 +934,7 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
   for (int c = 0; c < CHAINS; ++c) s[c] = *(lds_u32x4_ptr)(tops + (uint32_t)c * kRingTreeBytes + (rel[c] << 4));
 #pragma unroll
   for (uint32_t step = 1; step < kRingSteps; ++step) {
-    if (step == 2) __builtin_amdgcn_s_setprio(2);
+    if (step == 2 && !ahead) __builtin_amdgcn_s_setprio(2);
     super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
 #pragma unroll
     for (int c = 0; c < CHAINS; ++c) s[c] = *(lds_u32x4_ptr)(tops + (uint32_t)c * kRingTreeBytes + (rel[c] << 4));
@@ -943,7 +945,8 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & (kWave - 1)) == 0) ring_store(publish_to, publish_value);
   }
-  __builtin_amdgcn_s_setprio(3);      // the gathers of the deep steps first (see above)
+  if (ahead) __builtin_amdgcn_s_setprio(2);      // the gathers of the deep steps first (see above)
+  else __builtin_amdgcn_s_setprio(3);
   for (uint32_t step = kRingSteps; step < nsteps; ++step) {
     super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
 #pragma unroll
@@ -951,7 +954,7 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
       s[c] = __builtin_amdgcn_raw_buffer_load_b128(forest, (int)((h[c].base + rel[c]) << 4), 0, 0);
   }
   super_step<CHAINS, HAS_MISSING, true>(s, rel, leafb, tile_b);
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(1);      // the ring's bookkeeping between two groups is part of the walk (ring_walk_tile)
 #pragma unroll
   for (int c = 0; c < CHAINS; ++c)
     if ((uint32_t)c < ntrees_here) acc += __uint_as_float(leafb[c]);
@@ -965,16 +968,23 @@ __device__ __forceinline__ float ring_walk_tile(TopRing& rg, float acc, const fl
   for (uint32_t p = 0; p < rg.ngroups; ++p, ++rg.g) {
     const uint32_t g = rg.g;
     const uint32_t t = rg.t0 + p * kRingChains;
-    // ---- first at group g?  then group g + 1 is this wave's to stage
+    // ---- first at group g?  then group g + 1 is this wave's to stage.  The claim and the look at `filled` are one LDS
+    //      round trip, made at the walk's priority (a wave that comes out of a walk at priority 0 waits for every
+    //      walker on its SIMD before it may as much as ask): per-wave clocks showed 6 % of a wave's time in these two
+    //      questions (profiles/r04_sweeps.txt); 24.7 -> 24.4 ms, with `ahead` 24.3
     uint32_t won = 0;
-    if (g + 1u < rg.total && !rg.gave_up) {
-      if (lane == 0) {
-        uint32_t expected = g + 1u;
-        won = __hip_atomic_compare_exchange_strong(rg.claim, &expected, g + 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
-      }
-      won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
+    uint32_t filled_now = 0;
+    if (lane == 0) {
+      // the claim and the look at `filled` in one LDS round trip
+      uint32_t expected = g + 1u;
+      const bool may = g + 1u < rg.total && !rg.gave_up;
+      filled_now = ring_load(rg.filled);
+      if (may) won = __hip_atomic_compare_exchange_strong(rg.claim, &expected, g + 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
     }
+    won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
+    filled_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)filled_now);
+    if (won || filled_now < g + 1u) __builtin_amdgcn_s_setprio(0);      // about to wait or to stage: out of the walkers' way
     if (won) {
       // its buffer held group g + 1 - kRingBuffers: every wave must be done with that one
       const uint32_t need = g + 2u > kRingBuffers ? g + 2u - kRingBuffers : 0u;
@@ -987,14 +997,14 @@ __device__ __forceinline__ float ring_walk_tile(TopRing& rg, float acc, const fl
       ring_stage(rg, (p + 1 == rg.ngroups) ? rg.t0 : t + kRingChains, (g + 1u) % kRingBuffers, lane);
     }
     // ---- group g complete in the ring?
-    {
+    if (filled_now < g + 1u) {
       uint32_t spin = 0;
       while (ring_load(rg.filled) < g + 1u) {
         __builtin_amdgcn_s_sleep(1);
         if (++spin > kRingSpinLimit) { rg.gave_up = true; break; }
       }
-      ring_order();
     }
+    ring_order();       // the buffer is read after `filled` said so, not before
     // group g was complete before this wave walks it, so nobody else publishes meanwhile: g + 1 is next
     const lds_u32_ptr pub = won ? rg.filled : (lds_u32_ptr) nullptr;
     if (live && !rg.gave_up) {
@@ -1003,8 +1013,8 @@ __device__ __forceinline__ float ring_walk_tile(TopRing& rg, float acc, const fl
       for (int c = 0; c < kRingChains; ++c) h[c] = rg.heads[(t + c < rg.t1) ? t + c : rg.t1 - 1];
       const uint32_t here = rg.t1 - t < (uint32_t)kRingChains ? rg.t1 - t : (uint32_t)kRingChains;
       const lds_cptr buf = rg.ring + (g % kRingBuffers) * kRingBufBytes;
-      acc = wave_nan ? ring_walk_group<true>(h, here, rg.forest, tile, buf, acc, pub, g + 2u)
-                     : ring_walk_group<false>(h, here, rg.forest, tile, buf, acc, pub, g + 2u);
+      acc = wave_nan ? ring_walk_group<true>(h, here, rg.forest, tile, buf, acc, pub, g + 2u, won != 0u)
+                     : ring_walk_group<false>(h, here, rg.forest, tile, buf, acc, pub, g + 2u, won != 0u);
     } else if (won) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // a stager without a tile
       if (lane == 0) ring_store(rg.filled, g + 2u);
@@ -1012,6 +1022,7 @@ __device__ __forceinline__ float ring_walk_tile(TopRing& rg, float acc, const fl
     ring_order();                                             // the walk's reads of the buffer are done
     if (lane == 0) ring_store(rg.progress + wave, g + 1u);
   }
+  __builtin_amdgcn_s_setprio(0);
   return acc;
 }
 
