@@ -262,7 +262,7 @@ def pcie_inclusive(grid, booster, dev):
         t0 = time.perf_counter()
         d = capi.DMatrix(rows, missing=synth.XX_MISS)
         t1 = time.perf_counter()
-        booster.predict(d)
+        booster.predict(d, copy=False)         # the C call alone: the caller reads the booster's buffer in place (:362-374)
         t2 = time.perf_counter()
         d.free()
         ticks.append((time.perf_counter() - t0, t1 - t0, t2 - t1))

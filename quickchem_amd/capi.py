@@ -262,15 +262,18 @@ class Booster:
     def set_param(self, name: str, value) -> None:
         check(self.lib, self.lib.XGBoosterSetParam(self.handle, name.encode(), str(value).encode()))
 
-    def predict(self, dmat: DMatrix, option_mask: int = 0, ntree_limit: int = 0, training: int = 0) -> np.ndarray:
-        """Host result (copy of the booster-owned buffer), float32."""
+    def predict(self, dmat: DMatrix, option_mask: int = 0, ntree_limit: int = 0, training: int = 0,
+                copy: bool = True) -> np.ndarray:
+        """Host result, float32: a copy of the booster-owned buffer, or (copy=False) a view of it that is valid until
+        the booster's next predict - what the reference's Fortran reads through its c_f_pointer (OH_GridCompMod.F90:362)."""
         n = C.c_uint64()
         ptr = C.POINTER(C.c_float)()
         check(self.lib, self.lib.XGBoosterPredict(self.handle, dmat.handle, option_mask, ntree_limit, training,
                                                    C.byref(n), C.byref(ptr)))
         if n.value == 0:
             return np.empty(0, dtype=np.float32)
-        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+        view = np.ctypeslib.as_array(ptr, shape=(n.value,))
+        return view.copy() if copy else view
 
     def predict_device(self, dmat: DMatrix, out_ptr: int, option_mask: int = 0, ntree_limit: int = 0,
                        stream: int = 0) -> None:
