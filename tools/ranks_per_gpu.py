@@ -79,11 +79,12 @@ def child(args):
             for kv in args.param:
                 b.set_param(*kv.split("=", 1))
         d = capi.DMatrix(rows, missing=synth.XX_MISS)
-        p = b.predict(d)
+        p = b.predict(d, copy=False)                       # the caller reads the booster's buffer in place (:362-374)
         d.free()
         ticks["reference"].append(time.perf_counter() - t0)
         ends["reference"].append(time.time())
     t_ref1 = time.time()
+    p = p.copy()
     ref_sum = float(np.float64(p).sum())
     for tick in range(args.ticks):
         t0 = time.perf_counter()
