@@ -757,6 +757,14 @@ def main():
         if not np.array_equal(out_local[:n_chk].cpu().numpy().view(np.uint32), want.view(np.uint32)):
             raise SystemExit("bench: GPU margins differ from the oracle on the first rows of the batch")
         cpu["margins_bit_identical_on_first_rows"] = n_chk
+        # ... and on as many rows drawn from the whole batch (every level, every launch of the train)
+        pick = torch.randint(n_local, (n_chk,), device=dev, generator=torch.Generator(device=dev).manual_seed(2024))
+        od = capi.DMatrix(rows[pick].cpu().numpy(), missing=synth.XX_MISS, lib=lib)
+        want = ob.predict(od)
+        od.free()
+        if not np.array_equal(out_local[pick].cpu().numpy().view(np.uint32), want.view(np.uint32)):
+            raise SystemExit("bench: GPU margins differ from the oracle on rows drawn from the whole batch")
+        cpu["margins_bit_identical_on_random_rows"] = n_chk
 
     pcie = host_tick = None
     if rank == 0 and world == 1 and plain and not args.no_pcie and args.cpu_seconds > 0 and use_grid:
@@ -781,7 +789,8 @@ def main():
                           "build_s": round(t_model, 2)},
                 "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid), "grid_known_to_library": list(dmats[0].grid()), "verified": verified,
                 "verified_against": ("the whole timed output, bit for bit, against the `wide` kernel (other node format, no LDS tile, no grid hint); "
-                                     "the CPU oracle sees the first 2^18 rows (cpu_baseline.margins_bit_identical_on_first_rows)") if verified else None,
+                                     "the CPU oracle sees the first 2^18 rows and 2^18 rows drawn from the whole batch "
+                                     "(cpu_baseline.margins_bit_identical_on_first_rows / _on_random_rows)") if verified else None,
                 "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
                 "gather_via": (args.gather if (world > 1 or force_dist) else None),
             },
