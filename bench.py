@@ -729,11 +729,11 @@ def main():
 
     info = booster.info()
     symbol = booster.kernel_symbol(27)
-    # tiles per launch: the ring kernel takes 16 rounds (ohx_ring_rounds) of one 16-wave block per CU, the tile kernel
+    # tiles per launch: the ring kernel takes capi.RING_ROUNDS_DEFAULT rounds (ohx_ring_rounds) of one 16-wave block per CU, the tile kernel
     # 2 (ohx_launches_per_residency) of 20 waves per CU
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     knob = {kv.partition("=")[0]: kv.partition("=")[2] for kv in args.param}
-    rounds = int(knob.get("ohx_ring_rounds", 16)) if "ring" in symbol else int(knob.get("ohx_launches_per_residency", 2))
+    rounds = int(knob.get("ohx_ring_rounds", capi.RING_ROUNDS_DEFAULT)) if "ring" in symbol else int(knob.get("ohx_launches_per_residency", 2))
     per_launch = (cus * 16 if "ring" in symbol else cus * 20) * rounds if rounds > 0 else 1 << 62
     launches_per_step = sum(-(-((hi - lo + 63) // 64) // per_launch) for lo, hi in pieces)
     ms_per_step = elapsed / args.steps * 1e3

@@ -16,6 +16,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libohxgb.so")
+# the library's default of "ohx_ring_rounds" (csrc/kernels.hpp LaunchTuning::ring_rounds; tests/test_capi_host.py pins it)
+RING_ROUNDS_DEFAULT = 64
 
 # every symbol include/ohxgb.h declares
 ABI_SYMBOLS = [

@@ -788,8 +788,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
 // Every wait is on work with a lower group number, so the waves cannot wait in a circle; the spins are bounded all the
 // same and a wave that gives up raises kFlagRingTimeout (the host turns it into an error).
 //
-// C360 step: 27.4 ms against 31.1 (-12 %); depth 14: -3 %; depth 10: +8 % - the host picks these kernels for forests
-// of >= 7 steps per tree, as it does the tree tops (capi.cpp pick_kernel).
+// C360 step: 27.4 ms against the tile kernel's 31.1, and 24.3 with issue priorities (ring_walk_group); with them the ring
+// wins from 5 steps per tree on (depth 10: 13.8 against 14.2 ms; depth 8: 12.0 against 11.8), which is where the host
+// starts to pick these kernels (capi.cpp pick_kernel, kRingMinMeanSteps).
 constexpr int kRingChains = 4;
 constexpr int kRingWaves = 16;
 constexpr int kRingBlock = kRingWaves * kWave;

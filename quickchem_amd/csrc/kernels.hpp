@@ -164,8 +164,9 @@ struct LaunchTuning {
   int prefetch = 1;   // 27-column rows: prefetch the next tile's rows into registers during a walk
   int coop_rows = 1;  // ... fetched by the wave together where a tile is made of runs of >= 4 consecutive rows
   int lds_pad = 0;    // experiment knob: extra LDS bytes per block, to lower occupancy
-  // ring kernels: tiles per wave and launch (0 = one launch for the whole batch)
-  int ring_rounds = 16;
+  // ring kernels: tiles per wave and launch (0 = one launch for the whole batch).  C360 step 24.28 ms at 16, 24.13 at 64,
+  // 24.07 in one launch; the fused fields kernel 26.85 / 26.65 / 27.05 (profiles/r04_sweeps.txt)
+  int ring_rounds = 64;
   // small batches: trees split over several waves per tile (PredictArgs::leaf_buf): -1 = when the batch leaves half of
   // the chip's wave slots empty, 0 = never, n > 1 = always in n runs; needs the booster's leaf buffer
   int tree_split = -1;

@@ -191,3 +191,15 @@ def test_month_roll_over_policies_python_host(tmp_path, small_model, oracle_lib)
         assert len(p.boosters) == resident
     with pytest.raises(ValueError):
         oh_predict.OHPredictor(model_policy="sometimes")
+
+
+def test_python_side_knows_the_librarys_ring_rounds_default():
+    """bench.py turns kernel time into a per-launch duration with the number of launches a step makes; for the ring
+    kernels that follows from LaunchTuning::ring_rounds, which the Python side carries as capi.RING_ROUNDS_DEFAULT."""
+    import re
+    from quickchem_amd import capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hpp = open(os.path.join(root, "quickchem_amd", "csrc", "kernels.hpp")).read()
+    assert int(re.search(r"int ring_rounds = (\d+);", hpp).group(1)) == capi.RING_ROUNDS_DEFAULT
+    header = open(os.path.join(root, "include", "ohxgb.h")).read()
+    assert f'"ohx_ring_rounds" ring kernels: tiles per wavefront and launch (default {capi.RING_ROUNDS_DEFAULT};' in header
