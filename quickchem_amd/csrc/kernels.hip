@@ -378,12 +378,46 @@ __device__ __forceinline__ bool go_left_or_default(float x, float thr, bool defa
 // is 31" is taken exactly once per walk, at the leaf.  The fillers of one tree share a cache line, so
 // lanes that are done cost the L1 next to nothing.
 // LAST: the tree's final step - nothing is fetched after it, only the leaf is taken.
+// The missing-aware step keeps its decisions as LANE MASKS in scalar registers from the compare to the last use: the
+// compares are the mask-valued intrinsics, "right = not-less and (ordered or default-right)" is two scalar operations,
+// and the selects and the add-with-carry take the mask as it is (inline assembly: from a bool that is the AND / OR of
+// compares hipcc rebuilds every mask it needs with v_cndmask 0/1 + v_cmp_ne, 4 vector instructions per chain and
+// step).  21 vector instructions per chain and two-level step, against 25 as plain C and 14 for the walk without
+// missing values; C360 with 1e-3 of the entries missing (every tile walks this form): 34.6 -> 30.9 ms (profiles/r04_sweeps.txt;
+// behind a wave-uniform branch on "any lane read a NaN at this level": 30.8 ms at 1e-3, 33.3 against 31.3 at 1e-2, not kept).
+using lane_mask = uint64_t;
+constexpr int kFcmpOrdered = 7, kFcmpNotLess = 11 /* unordered or >= */, kIcmpEq = 32;
+
+// mask ? if_set : if_clear, per lane
+__device__ __forceinline__ uint32_t pick(lane_mask m, uint32_t if_clear, uint32_t if_set) {
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  return r;
+}
+
+// lanes that go RIGHT at a node: x is not less than the threshold and is a number, or x is missing and the node's
+// default is right (`default_left_bit` of `w` clear)
+__device__ __forceinline__ lane_mask right_or_default(float x, float thr, uint32_t w, uint32_t default_left_bit) {
+  const lane_mask not_less = __builtin_amdgcn_fcmpf(x, thr, kFcmpNotLess);
+  const lane_mask number = __builtin_amdgcn_fcmpf(x, x, kFcmpOrdered);
+  const lane_mask default_right = __builtin_amdgcn_uicmp(w & default_left_bit, 0u, kIcmpEq);
+  return not_less & (number | default_right);
+}
+
+// 2 v + carry-in, per lane
+__device__ __forceinline__ uint32_t double_and_carry(uint32_t v, lane_mask carry) {
+  uint32_t r;
+  asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(v), "s"(carry) : "vcc");
+  return r;
+}
+
 template <int CHAINS, bool HAS_MISSING, bool LAST>
 __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[CHAINS], uint32_t (&leafb)[CHAINS],
                                            const char* __restrict__ tile_b) {
   float x0[CHAINS], x1[CHAINS];
   uint32_t thr1[CHAINS], f1[CHAINS];
   bool l0[CHAINS];
+  lane_mask r0[CHAINS];
 #pragma unroll
   for (int c = 0; c < CHAINS; ++c) {
     asm volatile("" : "+v"(s[c]));   // one 128-bit tuple: see "pin_super" above
@@ -395,14 +429,17 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
 #pragma unroll
   for (int c = 0; c < CHAINS; ++c) {
     const uint32_t w = s[c].w;
-    bool l = x0[c] < __uint_as_float(s[c].x);
-    // missing (NaN) -> default child.  "not >=" is "<" for numbers and true for NaN, so the default
-    // direction only picks which of two compares counts; bitwise on purpose (no short-circuit: hipcc
-    // turns || and && over lane predicates into divergent branches)
-    if (HAS_MISSING) l = go_left_or_default(x0[c], __uint_as_float(s[c].x), (w & 32u) != 0u);
-    l0[c] = l;
-    thr1[c] = l ? s[c].y : s[c].z;
-    f1[c] = (w >> (l ? 0u : 13u)) & 31u;
+    if constexpr (HAS_MISSING) {
+      // missing (NaN) -> default child; bit 5 of w: the node's default is left
+      r0[c] = right_or_default(x0[c], __uint_as_float(s[c].x), w, 32u);
+      thr1[c] = pick(r0[c], s[c].y, s[c].z);
+      f1[c] = (w >> pick(r0[c], 0u, 13u)) & 31u;
+    } else {
+      const bool l = x0[c] < __uint_as_float(s[c].x);
+      l0[c] = l;
+      thr1[c] = l ? s[c].y : s[c].z;
+      f1[c] = (w >> (l ? 0u : 13u)) & 31u;
+    }
     if (!LAST) x1[c] = *reinterpret_cast<const float*>(tile_b + (f1[c] << 8));
   }
 #pragma unroll
@@ -410,18 +447,20 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
     const uint32_t w = s[c].w;
     leafb[c] = (f1[c] == 31u) ? thr1[c] : leafb[c];
     if (!LAST) {
-      bool l1 = x1[c] < __uint_as_float(thr1[c]);
-      if (HAS_MISSING) l1 = go_left_or_default(x1[c], __uint_as_float(thr1[c]), (w & (l0[c] ? 64u : 128u)) != 0u);
       // record number of the next step = 4 g + 2 (go right at the node) + (go right at the child), as two doublings with
       // the decisions carried in: two v_addc_co_u32 whose carry-in is the compare's lane mask - 14 VALU instructions per
       // chain and step instead of 16 (hipcc turns the C form, in whatever spelling, back into shifts, selects and ors);
       // depth 18 / 10 / 6: -0.4 / -1.7 / -1.8 %, the fused kernel -1.2 % (profiles/r04_sweeps.txt)
       const uint32_t g = w >> 18;
-      const uint64_t right0 = __builtin_amdgcn_ballot_w64(!l0[c]), right1 = __builtin_amdgcn_ballot_w64(!l1);
-      uint32_t t, r;
-      asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(t) : "v"(g), "s"(right0) : "vcc");
-      asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(r) : "v"(t), "s"(right1) : "vcc");
-      rel[c] = r;
+      if constexpr (HAS_MISSING) {
+        // bits 6 / 7 of w: the left / right child's default is left
+        const lane_mask r1 = right_or_default(x1[c], __uint_as_float(thr1[c]), w, pick(r0[c], 64u, 128u));
+        rel[c] = double_and_carry(double_and_carry(g, r0[c]), r1);
+      } else {
+        const bool l1 = x1[c] < __uint_as_float(thr1[c]);
+        const lane_mask right0 = __builtin_amdgcn_ballot_w64(!l0[c]), right1 = __builtin_amdgcn_ballot_w64(!l1);
+        rel[c] = double_and_carry(double_and_carry(g, right0), right1);
+      }
     }
   }
 }
