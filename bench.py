@@ -734,6 +734,9 @@ def main():
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     knob = {kv.partition("=")[0]: kv.partition("=")[2] for kv in args.param}
     rounds = int(knob.get("ohx_ring_rounds", capi.RING_ROUNDS_DEFAULT)) if "ring" in symbol else int(knob.get("ohx_launches_per_residency", 2))
+    if "ring" in symbol and (args.shuffle or args.consecutive):      # rows not known to lie on a grid keep short launches
+        clustered = args.shuffle and "ohx_cluster=off" not in args.param
+        rounds = min(rounds, capi.RING_ROUNDS_PERMUTED if clustered else capi.RING_ROUNDS_NO_GRID) if rounds > 0 else rounds
     per_launch = (cus * 16 if "ring" in symbol else cus * 20) * rounds if rounds > 0 else 1 << 62
     launches_per_step = sum(-(-((hi - lo + 63) // 64) // per_launch) for lo, hi in pieces)
     ms_per_step = elapsed / args.steps * 1e3

@@ -99,7 +99,8 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *                     trees at a time (the big batches of a 27-feature booster; everything else of such a booster
  *                     goes the super2 way).  auto = ring for 27-feature boosters of 5 or more steps per tree
  *                     (where it is faster: 20 % at the OH booster's 9 steps), else super2
- *   "ohx_ring_rounds" ring kernels: tiles per wavefront and launch (default 64; 0 = one launch)
+ *   "ohx_ring_rounds" ring kernels: tiles per wavefront and launch (default 64; 0 = one launch);
+ *                     at most 16 for rows not known to lie on a grid, 4 for rows in no order (clustering pass)
  *   "ohx_register_host"  0 | 1, process-wide (the handle may be NULL): the host arrays handed to OHXBoosterRun1,
  *                     OHXOHPostProcess and OHXBoosterPredictFields are registered with the GPU driver the first time
  *                     they are seen and moved by DMA - a rank-sized block's forty arrays by ONE copy launch - from

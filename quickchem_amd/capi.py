@@ -18,6 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libohxgb.so")
 # the library's default of "ohx_ring_rounds" (csrc/kernels.hpp LaunchTuning::ring_rounds; tests/test_capi_host.py pins it)
 RING_ROUNDS_DEFAULT = 64
+RING_ROUNDS_NO_GRID = 16      # kRingRoundsNoGrid: at most, for rows not known to lie on a grid
+RING_ROUNDS_PERMUTED = 4      # kRingRoundsPermuted: at most, for rows that come through the clustering pass
 
 # every symbol include/ohxgb.h declares
 ABI_SYMBOLS = [

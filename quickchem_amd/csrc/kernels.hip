@@ -1897,7 +1897,15 @@ hipError_t launch_rows_ring(const DeviceForest& fr, PredictArgs a, int num_cus, 
       a.run_lo_bits = a.shape.k_fastest ? a.shape.lk : 0u;
     }
   }
-  const uint64_t per_launch = tune.ring_rounds <= 0 ? ntiles : grid * kRingWaves * (uint64_t)tune.ring_rounds;
+  // rows that are not known to be neighbours on a grid (no hint and no level size found, or rows that come through the
+  // clustering pass's permutation) keep the short launches: what their lanes ask for has little in common, the XCD's L2
+  // is all they share, and it only holds while the blocks walk the same trees - shuffled C360 rows 47.2 ms at 16 rounds,
+  // 50.3 at 64 (without the clustering pass 84 against 125); rows on a grid 24.28 / 24.13 (profiles/r04_sweeps.txt)
+  // (through the permutation: 47.4 ms at 16, 45.9 at 4; 64 consecutive rows per wave: 34.05 at 16, 34.5 at 4)
+  int rounds = tune.ring_rounds;
+  const int no_grid = a.perm != nullptr ? kRingRoundsPermuted : kRingRoundsNoGrid;
+  if (a.shape.im == 0 && rounds > no_grid) rounds = no_grid;
+  const uint64_t per_launch = rounds <= 0 ? ntiles : grid * kRingWaves * (uint64_t)rounds;
   TrainCursor train(stream, tune);
   for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
     a.tile_begin = t0;

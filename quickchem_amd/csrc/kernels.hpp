@@ -149,6 +149,11 @@ struct TrainStreams {
   hipEvent_t fork = nullptr, join = nullptr;
 };
 
+// ring kernels: tiles per wave and launch at most, for rows not known to lie on a grid, and for rows that come through
+// the clustering pass's permutation (launch_rows_ring)
+constexpr int kRingRoundsNoGrid = 16;
+constexpr int kRingRoundsPermuted = 4;
+
 struct LaunchTuning {
   // 0: one launch for the whole batch (waves stride over tiles).  > 0: one launch per this many
   // "waves of tiles": every launch starts all resident waves on tree 0 together, so the waves of

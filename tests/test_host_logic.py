@@ -201,5 +201,7 @@ def test_python_side_knows_the_librarys_ring_rounds_default():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hpp = open(os.path.join(root, "quickchem_amd", "csrc", "kernels.hpp")).read()
     assert int(re.search(r"int ring_rounds = (\d+);", hpp).group(1)) == capi.RING_ROUNDS_DEFAULT
+    assert int(re.search(r"constexpr int kRingRoundsNoGrid = (\d+);", hpp).group(1)) == capi.RING_ROUNDS_NO_GRID
+    assert int(re.search(r"constexpr int kRingRoundsPermuted = (\d+);", hpp).group(1)) == capi.RING_ROUNDS_PERMUTED
     header = open(os.path.join(root, "include", "ohxgb.h")).read()
     assert f'"ohx_ring_rounds" ring kernels: tiles per wavefront and launch (default {capi.RING_ROUNDS_DEFAULT};' in header
