@@ -1656,10 +1656,23 @@ __global__ __launch_bounds__(kBlock) void k_slab_kernel(SlabArgs a) {
     const float tp = a.tropp[col];
     const float lim = a.dynamic_k_range ? tp : a.tropp_min;
     bad += (tp <= a.tropp_min) ? 1 : 0;
+    // a column's km + 1 edges, each read once, eight in flight (one after the other a rank-sized block - a handful of
+    // waves on the whole chip - spent 16 us here on 146 dependent-looking loads per column)
     int cnt = 0;
-    for (int k = 0; k < a.km; ++k) {
-      const float pl = (a.ple_mod[col + plane * (uint64_t)k] + a.ple_mod[col + plane * (uint64_t)(k + 1)]) * 0.5f;
-      cnt += (pl > lim) ? 1 : 0;
+    float upper = a.ple_mod[col];
+    for (int k0 = 0; k0 < a.km; k0 += 8) {
+      float e[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {      // (past the column's end: its last edge again, loaded and not counted - no branches)
+        const int edge = k0 + d + 1 < a.km ? k0 + d + 1 : a.km;
+        e[d] = a.ple_mod[col + plane * (uint64_t)edge];
+      }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const float pl = (upper + e[d]) * 0.5f;
+        cnt += (k0 + d < a.km && pl > lim) ? 1 : 0;
+        upper = e[d];
+      }
     }
     best = cnt > best ? cnt : best;
   }

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""A GEOS rank's OH tick, alone on the GPU, for a look at its kernels (measurement aid): OHXBoosterRun1's HOST form on one
+rank-sized block (default 48 x 24 x 72) whose arrays are registered (ohx_register_host), --ticks times; prints the median
+tick.  Under `rocprofv3 --kernel-trace --stats -- python3 tools/run1_block_ticks.py` the per-kernel averages say where
+the device side of a tick goes.  usage (GPU box): python3 tools/run1_block_ticks.py [--block 48,24,72] [--ticks 200]
+[--param name=value ...]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--block", default="48,24,72")
+    ap.add_argument("--ticks", type=int, default=200)
+    ap.add_argument("--trees", type=int, default=100)
+    ap.add_argument("--depth", type=int, default=18)
+    ap.add_argument("--param", action="append", default=[])
+    args = ap.parse_args()
+    from quickchem_amd import capi, synth
+    block = tuple(int(x) for x in args.block.split(","))
+    model = synth.make_model(num_trees=args.trees, max_depth=args.depth, sample_log2=20)
+    booster = capi.Booster(model_buffer=model.image)
+    booster.set_param("ohx_register_host", "1")
+    for kv in args.param:
+        name, _, val = kv.partition("=")
+        booster.set_param(name, val)
+    st = synth.run1_state(block, seed=5)
+    call = booster.run1_prepare(st, dynamic_k_range=True)
+    ticks = []
+    for _ in range(args.ticks):
+        t0 = time.perf_counter()
+        r = booster.run1_call(call)
+        ticks.append(time.perf_counter() - t0)
+    print(f"block {block}: levels {int(r['k1'])}..{int(r['k2'])}, tick median {np.median(ticks[5:]) * 1e3:.3f} ms, "
+          f"p95 {np.percentile(ticks[5:], 95) * 1e3:.3f} ms over {args.ticks - 5} ticks")
+
+
+if __name__ == "__main__":
+    main()
