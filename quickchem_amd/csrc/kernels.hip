@@ -169,6 +169,45 @@ __device__ __forceinline__ bool fill_tile_fields(const FieldsArgs& a, float* __r
   return lane_nan;
 }
 
+// The same for a SMALL slab (a GEOS rank's block; PredictArgs::leaf_buf: a tile is filled by every wave that walks a run
+// of its trees): nine loads in flight at a time.  There the chip is far from full, nobody's gathers stand behind a burst
+// of loads, and 27 round trips in a row were a tenth of the kernel (48 x 24 x 72 block: 74 -> 67 us; profiles/r04_sweeps.txt).
+__device__ __forceinline__ bool fill_tile_fields_burst(const FieldsArgs& a, float* __restrict__ tile, uint32_t nfeat, uint64_t m,
+                                                       uint64_t col, uint64_t slab, bool valid, bool missing_is_nan) {
+  constexpr uint32_t GROUP = 9;
+  const float qnan = __builtin_nanf("");
+  bool lane_nan = false, any_inf = false;
+  const uint64_t at3 = valid ? slab + m : slab, at2 = valid ? col : 0;      // a lane without a gridcell: the slab's first
+  for (uint32_t f0 = 0; f0 < nfeat; f0 += GROUP) {
+    float x[GROUP];
+#pragma unroll
+    for (uint32_t g = 0; g < GROUP; ++g) {
+      const uint32_t f = f0 + g;
+      x[g] = qnan;
+      if (f < nfeat && f < a.nfield) {
+        const float* src = a.field[f];
+        x[g] = ((a.is2d_mask >> f) & 1u) ? src[at2] : __builtin_nontemporal_load(src + at3);
+      }
+    }
+#pragma unroll
+    for (uint32_t g = 0; g < GROUP; ++g) {
+      const uint32_t f = f0 + g;
+      float v = x[g];
+      if (f == a.pl_feature) {
+        asm volatile("");      // a branch, taken for one field, not a division computed for all and selected
+        v = v / 100.0f;
+      }
+      any_inf |= f < nfeat && is_inf(v);
+      if (!missing_is_nan && v == a.missing) v = qnan;
+      if (!valid) v = 0.0f;
+      lane_nan |= f < nfeat && (v != v);
+      if (f < nfeat) tile[f * kWave] = v;
+    }
+  }
+  if (any_inf && !is_inf(a.missing) && a.flags) atomicOr(a.flags, kFlagInfInput);
+  return lane_nan;
+}
+
 // what the fused path stores for a gridcell: the margin (optional) and 10**margin * OHscale (:369, :1569)
 __device__ __forceinline__ void store_oh(const FieldsArgs& a, float* __restrict__ out, float* __restrict__ margin_out,
                                          uint64_t slab_out, uint64_t m, float acc) {
@@ -1293,7 +1332,7 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
         bool valid;
         const uint64_t m = tile_row(a.shape, tile_id, lane, nrow, &valid);
         if (!__any(valid) || t0 >= t1) continue;
-        const bool lane_nan = fill_tile_fields(a, tile, fr.num_feature, m, valid ? m % plane : 0, slab, valid, missing_is_nan);
+        const bool lane_nan = fill_tile_fields_burst(a, tile, fr.num_feature, m, valid ? m % plane : 0, slab, valid, missing_is_nan);
         float* leaves = a.leaf_buf + ((size_t)(tile_id - a.tile_begin) * ntree - a.tree_begin) * kWave + lane;
         (void)walk_tile<FMT, CHAINS, TOPS>(fr, heads, t0, t1, tile, __any(lane_nan), first, nfirst, leaves);
       }
