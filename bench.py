@@ -70,7 +70,7 @@ def parse_args():
                          "for the level size by itself")
     ap.add_argument("--consecutive", action="store_true",
                     help="rows path: tell the library there is no grid (OHXDMatrixSetGrid(0,0)): 64 consecutive rows per wave")
-    ap.add_argument("--gather-chunks", type=int, default=4,
+    ap.add_argument("--gather-chunks", type=int, default=6,
                     help="N > 1: cut the shard into this many pieces so that a piece's all-gather overlaps the next "
                          "piece's prediction (1 = predict everything, then one all-gather)")
     ap.add_argument("--gather", default="torch", choices=["torch", "native", "none"],
@@ -637,7 +637,7 @@ def main():
     # one residency of the chip: 20 waves per CU for the tile kernels, one 16-wave block per CU for the ring kernels
     waves_per_cu = 16 if "ring" in booster.kernel_symbol(27) else 20
     round_rows = torch.cuda.get_device_properties(dev).multi_processor_count * waves_per_cu * 64
-    pieces = shard.plan_pieces(n_local, args.gather_chunks if (gather and even) else 1, granule, round_rows)
+    pieces = shard.plan_pieces(n_local, args.gather_chunks if (gather and even) else 1, granule, round_rows, world)
     dmats = [capi.DMatrix(device_ptr=rows.data_ptr() + lo * synth.NFEAT * 4, nrow=hi - lo, ncol=synth.NFEAT,
                           missing=synth.XX_MISS) for lo, hi in pieces]
     if use_grid:

@@ -62,17 +62,34 @@ def chunk_bounds(n_local: int, nchunks: int, granule: int) -> list:
     return out
 
 
-def plan_pieces(n_local: int, max_pieces: int, granule: int, round_rows: int) -> list:
+# plan_pieces' price list, in rounds of the chip (one residency's rows walked through the OH booster, ~0.11 ms on an MI355X):
+WALK_ROWS_PER_S = 2.3e9          # bench.py, C360 step
+GATHER_BYTES_PER_S = 100e9       # what one rank takes in during an all-gather over xGMI - a guess on the safe side, no
+                                 # N > 1 run has been measured
+PIECE_ROUNDS = 0.3               # one more launch, one more collective enqueued
+
+
+def plan_pieces(n_local: int, max_pieces: int, granule: int, round_rows: int, world: int = 1) -> list:
     """Cut [0, n_local) into at most `max_pieces` pieces of whole granules (a grid level when the
-    waves take bricks) so that the pieces' all-gathers can overlap the next piece's prediction,
-    WITHOUT paying for it in idle waves: a piece occupies the GPU for ceil(rows / round_rows) rounds
-    (round_rows = rows one residency of the chip covers, 256 CUs x 20 waves x 64), so the plan with
-    the fewest rounds wins and, among equals, the one with the most pieces.  C360/8 = 9 levels:
-    three pieces of 3 levels take 24 rounds, two of 5 + 4 take 22, like the uncut shard."""
+    waves take bricks) so that the pieces' all-gathers can overlap the next piece's prediction.
+    A piece occupies the GPU for ceil(rows / round_rows) rounds (round_rows = rows one residency of
+    the chip covers).  world <= 1 (nothing to gather, or unknown): the plan with the fewest rounds
+    wins and, among equals, the one with the most pieces.  world > 1: every plan is priced in
+    rounds - its own, plus the all-gather of its LAST piece, which nothing hides (rows x 4 B x
+    (world - 1) at GATHER_BYTES_PER_S), plus PIECE_ROUNDS per piece - and the cheapest wins: an
+    extra round is worth paying when it shrinks what stays exposed (C360 on 2 GPUs: one piece of 36
+    levels would leave 112 MB per rank unhidden; four of 9 cost one round more of 107)."""
     if max_pieces <= 1 or granule <= 0 or n_local <= granule:
         return [(0, n_local)]
     units = -(-n_local // granule)
+
+    def exposed(last_rows):
+        if world <= 1:
+            return 0.0
+        return last_rows * 4.0 * (world - 1) / GATHER_BYTES_PER_S / (round_rows / WALK_ROWS_PER_S)
+
     best, best_rounds = [(0, n_local)], -(-n_local // round_rows)
+    best_cost = best_rounds + exposed(n_local) + PIECE_ROUNDS
     for k in range(2, min(max_pieces, units) + 1):
         base, rem = divmod(units, k)
         sizes = [(base + (1 if q < rem else 0)) * granule for q in range(k)]
@@ -82,8 +99,13 @@ def plan_pieces(n_local: int, max_pieces: int, granule: int, round_rows: int) ->
             out.append((lo, hi))
             lo = hi
         rounds = sum(-(-(hi - lo) // round_rows) for lo, hi in out)
-        if rounds <= best_rounds:
-            best, best_rounds = out, rounds
+        if world <= 1:
+            if rounds <= best_rounds:
+                best, best_rounds = out, rounds
+        else:
+            cost = rounds + exposed(out[-1][1] - out[-1][0]) + PIECE_ROUNDS * k
+            if cost < best_cost - 1e-9:
+                best, best_cost = out, cost
     return best
 
 

@@ -43,6 +43,20 @@ def test_plan_pieces_never_costs_rounds():
     assert p[-1][1] == 10 * plane + 17
 
 
+def test_plan_pieces_prices_the_gather_nothing_hides():
+    """With a world to gather over, a plan is priced: its rounds, the all-gather of its last piece, a little per piece.
+    C360 on the ring kernels' rounds (one 16-wave block per CU)."""
+    plane, rr = 360 * 2160, 256 * 16 * 64
+    for world, max_pieces, want in ((2, 4, [9, 9, 9, 9]), (4, 4, [5, 5, 4, 4]), (8, 4, [3, 2, 2, 2]), (8, 6, [2, 2, 2, 2, 1])):
+        n = 72 // world * plane
+        p = shard.plan_pieces(n, max_pieces, plane, rr, world)
+        assert p[0][0] == 0 and p[-1][1] == n and all(a[1] == b[0] for a, b in zip(p, p[1:]))
+        assert [(hi - lo) // plane for lo, hi in p] == want
+        assert sum(-(-(hi - lo) // rr) for lo, hi in p) <= -(-n // rr) + 1          # at most one round dearer than uncut
+    assert shard.plan_pieces(36 * plane, 4, plane, rr, 1) == [(0, 36 * plane)]      # nothing to gather: rounds decide
+    assert shard.plan_pieces(plane, 6, plane, rr, 8) == [(0, plane)]
+
+
 def test_chunk_bounds_cover_the_shard():
     for n_local in (1, 639, 640, 641, 6_998_400, 53_265_600):
         for k in (1, 2, 4, 7):
