@@ -636,7 +636,8 @@ def main():
     granule = plane if (use_grid and row0 % plane == 0 and n_local % plane == 0) else 64 * 256 * 20 * 2
     # one residency of the chip: 20 waves per CU for the tile kernels, one 16-wave block per CU for the ring kernels
     waves_per_cu = 16 if "ring" in booster.kernel_symbol(27) else 20
-    round_rows = torch.cuda.get_device_properties(dev).multi_processor_count * waves_per_cu * 64
+    reserve = int({kv.partition("=")[0]: kv.partition("=")[2] for kv in args.param}.get("ohx_reserve_cus", 0)) if waves_per_cu == 16 else 0
+    round_rows = (torch.cuda.get_device_properties(dev).multi_processor_count - reserve) * waves_per_cu * 64
     pieces = shard.plan_pieces(n_local, args.gather_chunks if (gather and even) else 1, granule, round_rows, world)
     dmats = [capi.DMatrix(device_ptr=rows.data_ptr() + lo * synth.NFEAT * 4, nrow=hi - lo, ncol=synth.NFEAT,
                           missing=synth.XX_MISS) for lo, hi in pieces]
@@ -737,7 +738,8 @@ def main():
     if "ring" in symbol and (args.shuffle or args.consecutive):      # rows not known to lie on a grid keep short launches
         clustered = args.shuffle and "ohx_cluster=off" not in args.param
         rounds = min(rounds, capi.RING_ROUNDS_PERMUTED if clustered else capi.RING_ROUNDS_NO_GRID) if rounds > 0 else rounds
-    per_launch = (cus * 16 if "ring" in symbol else cus * 20) * rounds if rounds > 0 else 1 << 62
+    ring_cus = cus - int(knob.get("ohx_reserve_cus", 0))
+    per_launch = (ring_cus * 16 if "ring" in symbol else cus * 20) * rounds if rounds > 0 else 1 << 62
     launches_per_step = sum(-(-((hi - lo + 63) // 64) // per_launch) for lo, hi in pieces)
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total / (elapsed / args.steps)

@@ -101,6 +101,9 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *                     (where it is faster: 20 % at the OH booster's 9 steps), else super2
  *   "ohx_ring_rounds" ring kernels: tiles per wavefront and launch (default 64; 0 = one launch);
  *                     at most 16 for rows not known to lie on a grid, 4 for rows in no order (clustering pass)
+ *   "ohx_reserve_cus" ring kernels (rows): compute units left free, 0..128 (default 0).  A ring block owns its CU for the
+ *                     length of a launch; a collective enqueued beside the predict (OHXAllGatherOH, torch.distributed)
+ *                     otherwise only gets on the chip at a launch boundary
  *   "ohx_register_host"  0 | 1, process-wide (the handle may be NULL): the host arrays handed to OHXBoosterRun1,
  *                     OHXOHPostProcess and OHXBoosterPredictFields are registered with the GPU driver the first time
  *                     they are seen and moved by DMA - a rank-sized block's forty arrays by ONE copy launch - from

@@ -1204,6 +1204,9 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     // process-wide (the host form of OHXOHPostProcess has no booster): see HostRegistry
     g_host_registry.on.store(atoi(value) != 0);
     if (atoi(value) == 0) g_host_registry.release_all();
+  } else if (n == "ohx_reserve_cus") {
+    b->tune.reserve_cus = atoi(value);
+    if (b->tune.reserve_cus < 0 || b->tune.reserve_cus > 128) throw OhxError("ohx_reserve_cus must be 0..128");
   } else if (n == "ohx_ring_rounds") {
     b->tune.ring_rounds = atoi(value);
     if (b->tune.ring_rounds < 0) throw OhxError("ohx_ring_rounds must be >= 0");

@@ -1937,7 +1937,8 @@ hipError_t launch_rows_ring(const DeviceForest& fr, PredictArgs a, int num_cus, 
   shape_rows(a, tune);
   const uint64_t ntiles = a.shape.ntiles(a.nrow);
   uint64_t grid = (ntiles + kRingWaves - 1) / kRingWaves;
-  if (grid > (uint64_t)num_cus) grid = (uint64_t)num_cus;
+  const uint64_t cus = tune.reserve_cus > 0 && tune.reserve_cus < num_cus ? (uint64_t)(num_cus - tune.reserve_cus) : (uint64_t)num_cus;
+  if (grid > cus) grid = cus;
   a.xcd_remap = tune.xcd_remap;
   a.run_log = 0;
   a.run_lo_bits = 0;

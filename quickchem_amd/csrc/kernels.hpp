@@ -172,6 +172,9 @@ struct LaunchTuning {
   // ring kernels: tiles per wave and launch (0 = one launch for the whole batch).  C360 step 24.28 ms at 16, 24.13 at 64,
   // 24.07 in one launch; the fused fields kernel 26.85 / 26.65 / 27.05 (profiles/r04_sweeps.txt)
   int ring_rounds = 64;
+  // ring kernels: CUs left free (a ring block owns its CU - all of its vector registers and LDS - for the length of a
+  // launch, so a collective's kernels enqueued beside it only get on the chip at a launch boundary; 0 = take them all)
+  int reserve_cus = 0;
   // small batches: trees split over several waves per tile (PredictArgs::leaf_buf): -1 = when the batch leaves half of
   // the chip's wave slots empty, 0 = never, n > 1 = always in n runs; needs the booster's leaf buffer
   int tree_split = -1;

@@ -756,7 +756,8 @@ def test_ring_rows_vs_oracle_ragged_sizes(torch_cuda, deep_model, small_model, n
     for image in (deep_model.image, small_model.image):
         want = helpers.oracle_predict(image, rows, synth.XX_MISS)
         for hint, extra in (((0, 0, 0), {}), ((96, 72, 777), {}), ((96, 72, 777), {"ohx_ring_rounds": 1}),
-                            ((96, 72, 777), {"ohx_ring_rounds": 0}), ((96, 72, 777), {"ohx_xcd_remap": 0})):
+                            ((96, 72, 777), {"ohx_ring_rounds": 0}), ((96, 72, 777), {"ohx_xcd_remap": 0}),
+                            ((96, 72, 777), {"ohx_reserve_cus": 16})):
             got = gpu_predict(image, rows, synth.XX_MISS, "ring", params=dict(RING, **extra), grid=hint)
             assert np.array_equal(helpers.bits(got), helpers.bits(want)), (hint, extra)
 
