@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--trees", type=int, default=100)
     ap.add_argument("--depth", type=int, default=18)
     ap.add_argument("--param", action="append", default=[])
+    ap.add_argument("--ab", default="", help="name=a,b: alternate two values of a parameter from tick to tick and report both")
     args = ap.parse_args()
     from quickchem_amd import capi, synth
     block = tuple(int(x) for x in args.block.split(","))
@@ -32,6 +33,20 @@ def main():
         booster.set_param(name, val)
     st = synth.run1_state(block, seed=5)
     call = booster.run1_prepare(st, dynamic_k_range=True)
+    if args.ab:
+        # two settings of one parameter, tick about: the drift of a box over a minute cancels
+        name, _, vals = args.ab.partition("=")
+        a, b2 = vals.split(",")
+        t = {a: [], b2: []}
+        for i in range(2 * args.ticks):
+            v = (a, b2)[i & 1]
+            booster.set_param(name, v)
+            t0 = time.perf_counter()
+            r = booster.run1_call(call)
+            t[v].append(time.perf_counter() - t0)
+        for v in (a, b2):
+            print(f"block {block}: {name}={v}: tick median {np.median(t[v][5:]) * 1e3:.3f} ms, p95 {np.percentile(t[v][5:], 95) * 1e3:.3f} ms")
+        return
     ticks = []
     for _ in range(args.ticks):
         t0 = time.perf_counter()
