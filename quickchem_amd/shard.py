@@ -66,7 +66,8 @@ def chunk_bounds(n_local: int, nchunks: int, granule: int) -> list:
 WALK_ROWS_PER_S = 2.3e9          # bench.py, C360 step
 GATHER_BYTES_PER_S = 100e9       # what one rank takes in during an all-gather over xGMI - a guess on the safe side, no
                                  # N > 1 run has been measured
-PIECE_ROUNDS = 0.3               # one more launch, one more collective enqueued
+PIECE_ROUNDS = 0.4               # one more launch, one more collective enqueued: 40-45 us a piece, measured on a C360/8 shard
+                                 # with one-rank RCCL (profiles/r04_sweeps.txt)
 
 
 def plan_pieces(n_local: int, max_pieces: int, granule: int, round_rows: int, world: int = 1) -> list:
