@@ -302,6 +302,26 @@ struct HostMover {
     (void)hipGetLastError();
     HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(float), to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream));
   }
+  // `count` floats at `offset` of a host array of `whole` floats that is registered as a whole (a k-slab of a MAPL field)
+  void add_slice(float* dev, const float* host_base, size_t whole, size_t offset, size_t count) {
+    if (count == 0) return;
+    void* mapped = nullptr;
+    if (g_host_registry.want(host_base, whole * sizeof(float)) && list.count < kCopyListMax &&
+        list_bytes + count * sizeof(float) <= kKernelBytesMax &&
+        hipHostGetDevicePointer(&mapped, const_cast<float*>(host_base), 0) == hipSuccess && mapped != nullptr) {
+      float* m = static_cast<float*>(mapped) + offset;
+      list.src[list.count] = to_device ? m : dev;
+      list.dst[list.count] = to_device ? dev : m;
+      list.n[list.count] = count;
+      ++list.count;
+      list_bytes += count * sizeof(float);
+      return;
+    }
+    (void)hipGetLastError();
+    float* host = const_cast<float*>(host_base) + offset;
+    HIP_CHECK(hipMemcpyAsync(to_device ? (void*)dev : (void*)host, to_device ? (const void*)host : (const void*)dev,
+                             count * sizeof(float), to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream));
+  }
   void go() {
     HIP_CHECK(launch_copy_arrays(list, stream));
     list.count = 0;
@@ -1362,15 +1382,32 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
     HIP_CHECK(hipStreamCreateWithFlags(&b->s_copy, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&b->s_exec, hipStreamNonBlocking));
   }
+  // pieces of at least two residencies of rows (the launch granule), at most 8 pieces
+  const size_t min_rows = (size_t)64 * 256 * 20 * 2;
+  size_t lev_per_piece = (min_rows + plane - 1) / plane;
+  if (lev_per_piece * 8 < nlev) lev_per_piece = (nlev + 7) / 8;
+  if (lev_per_piece < 1) lev_per_piece = 1;
+  // A rank-sized block is ONE piece, and with the caller's arrays registered its 27 fields cross in one copy launch
+  // (HostMover) instead of 27 copies at 27 fixed prices: a 48 x 24 x 72 block 0.55 -> 0.33 ms, 96 x 48 x 72 1.26 -> 1.03
+  // (profiles/r04_sweeps.txt; the reference's five calls: 0.35 and 1.02)
+  const bool registered = g_host_registry.on.load(std::memory_order_relaxed);
+  const bool one_launch = registered && lev_per_piece >= nlev && nfield <= (int)kCopyListMax &&
+                          ((size_t)nfield * nrow + nrow * 2) * sizeof(float) <= HostMover::kKernelBytesMax;
+  HostMover in(b->s_exec, true);
   for (int f = 0; f < nfield; ++f) {
     if (fields[f] == nullptr) throw OhxError("predict_fields: field " + std::to_string(f) + " is NULL");
     b->d_stage[(size_t)f].ensure(is2d[f] ? plane : nrow);
     a.field[f] = b->d_stage[(size_t)f].p;
-    if (is2d[f])
+    if (one_launch) {
+      if (is2d[f]) in.add(b->d_stage[(size_t)f].p, fields[f], plane);
+      else in.add_slice(b->d_stage[(size_t)f].p, fields[f], plane * (size_t)km, plane * (size_t)a.k1, nrow);
+    } else if (is2d[f]) {
       upload_host_array(b->d_stage[(size_t)f].p, fields[f], plane, b->s_copy);
-    else if (g_host_registry.on.load(std::memory_order_relaxed))
+    } else if (registered) {
       (void)g_host_registry.want(fields[f], plane * (size_t)km * sizeof(float));       // the whole field once, not per piece
+    }
   }
+  if (one_launch) in.go();
   a.src_k0 = a.k1;
   a.out_k0 = a.k1;
   b->d_stage_out.ensure(nrow);
@@ -1380,17 +1417,12 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
     a.margin_out = b->d_stage_margin.p;
   }
   if (pick_kernel(*b) == KernelKind::Wide) ensure_wide(*b);
-  // pieces of at least two residencies of rows (the launch granule), at most 8 pieces
-  const size_t min_rows = (size_t)64 * 256 * 20 * 2;
-  size_t lev_per_piece = (min_rows + plane - 1) / plane;
-  if (lev_per_piece * 8 < nlev) lev_per_piece = (nlev + 7) / 8;
-  if (lev_per_piece < 1) lev_per_piece = 1;
   const float* margin_base = a.margin_out;
   std::vector<hipEvent_t> events;
   for (size_t l0 = 0; l0 < nlev; l0 += lev_per_piece) {
     const size_t l1 = std::min(nlev, l0 + lev_per_piece);
     for (int f = 0; f < nfield; ++f) {
-      if (is2d[f]) continue;
+      if (is2d[f] || one_launch) continue;
       const float* src = fields[f] + plane * ((size_t)a.k1 + l0);
       HIP_CHECK(hipMemcpyAsync(b->d_stage[(size_t)f].p + plane * l0, src, plane * (l1 - l0) * sizeof(float),
                                hipMemcpyHostToDevice, b->s_copy));
@@ -1412,14 +1444,21 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
     HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), piece, b->dev.num_cus, b->s_exec, tune));
     if (deferring) defer_look(*b, piece_rows, b->s_exec);
   }
-  if (g_host_registry.on.load(std::memory_order_relaxed)) {
-    (void)g_host_registry.want(oh_ml, plane * (size_t)km * sizeof(float));
-    if (margin) (void)g_host_registry.want(margin, nrow * sizeof(float));
+  if (one_launch) {
+    HostMover back(b->s_exec, false);
+    back.add_slice(b->d_stage_out.p, oh_ml, plane * (size_t)km, plane * (size_t)a.k1, nrow);
+    if (margin) back.add(margin, b->d_stage_margin.p, nrow);
+    back.go();
+  } else {
+    if (registered) {
+      (void)g_host_registry.want(oh_ml, plane * (size_t)km * sizeof(float));
+      if (margin) (void)g_host_registry.want(margin, nrow * sizeof(float));
+    }
+    HIP_CHECK(hipMemcpyAsync(oh_ml + plane * (size_t)a.k1, b->d_stage_out.p, nrow * sizeof(float), hipMemcpyDeviceToHost,
+                             b->s_exec));
+    if (margin)
+      HIP_CHECK(hipMemcpyAsync(margin, b->d_stage_margin.p, nrow * sizeof(float), hipMemcpyDeviceToHost, b->s_exec));
   }
-  HIP_CHECK(hipMemcpyAsync(oh_ml + plane * (size_t)a.k1, b->d_stage_out.p, nrow * sizeof(float), hipMemcpyDeviceToHost,
-                           b->s_exec));
-  if (margin)
-    HIP_CHECK(hipMemcpyAsync(margin, b->d_stage_margin.p, nrow * sizeof(float), hipMemcpyDeviceToHost, b->s_exec));
   HIP_CHECK(hipStreamSynchronize(b->s_exec));
   for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
   raise_flag_errors(*b, b->s_exec);

@@ -325,10 +325,14 @@ def test_host_forms_with_registered_arrays(small_model):
         for mode in ("1", "0"):
             b.set_param("ohx_register_host", mode)
             oh = np.zeros(g2[0] * g2[1] * g2[2], dtype=np.float32)
+            margin = np.zeros(g2[0] * g2[1] * (g2[2] - 4), dtype=np.float32)
             for _ in range(2):
-                b.predict_fields(ff, synth.IS2D, synth.PL_FEATURE, *g2, 5, g2[2], synth.XX_MISS, oh, ohscale=0.85)
-            res[mode] = oh
-        assert np.array_equal(helpers.bits(res["1"]), helpers.bits(res["0"])) and np.any(res["1"] != 0)
+                b.predict_fields(ff, synth.IS2D, synth.PL_FEATURE, *g2, 5, g2[2], synth.XX_MISS, oh, ohscale=0.85, margin=margin)
+            res[mode] = (oh, margin)
+        # (registered, a rank-sized block's k-slab of every field and the outputs cross in one copy launch each way)
+        assert np.array_equal(helpers.bits(res["1"][0]), helpers.bits(res["0"][0])) and np.any(res["1"][0] != 0)
+        assert np.array_equal(helpers.bits(res["1"][1]), helpers.bits(res["0"][1])) and np.any(res["1"][1] != 0)
+        assert np.all(res["1"][0][:g2[0] * g2[1] * 4] == 0)              # the levels above the slab are not touched
     finally:
         b.set_param("ohx_register_host", "0")
         b.free()

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--trees", type=int, default=100)
     ap.add_argument("--depth", type=int, default=18)
     ap.add_argument("--param", action="append", default=[])
+    ap.add_argument("--call", default="run1", choices=["run1", "fused"], help="OHXBoosterRun1 (default) or OHXBoosterPredictFields, host forms")
     ap.add_argument("--ab", default="", help="name=a,b: alternate two values of a parameter from tick to tick and report both")
     args = ap.parse_args()
     from quickchem_amd import capi, synth
@@ -31,8 +32,21 @@ def main():
     for kv in args.param:
         name, _, val = kv.partition("=")
         booster.set_param(name, val)
-    st = synth.run1_state(block, seed=5)
-    call = booster.run1_prepare(st, dynamic_k_range=True)
+    if args.call == "fused":
+        # the fused predict-only call from host arrays (OHXBoosterPredictFields): 27 fields in, OH_ML out, all levels
+        im, jm, km = block
+        fields = [np.ascontiguousarray(synth.field_cpu(block, f).T) for f in range(synth.NFEAT)]
+        oh = np.zeros((km, jm, im), dtype=np.float32)
+
+        class Fused:
+            def run1_call(self, _):
+                booster.predict_fields(fields, synth.IS2D, synth.PL_FEATURE, im, jm, km, 1, km, synth.XX_MISS, oh, ohscale=0.85)
+                return {"k1": 1, "k2": km}
+        runner, call = Fused(), None
+    else:
+        st = synth.run1_state(block, seed=5)
+        call = booster.run1_prepare(st, dynamic_k_range=True)
+        runner = booster
     if args.ab:
         # two settings of one parameter, tick about: the drift of a box over a minute cancels
         name, _, vals = args.ab.partition("=")
@@ -42,7 +56,7 @@ def main():
             v = (a, b2)[i & 1]
             booster.set_param(name, v)
             t0 = time.perf_counter()
-            r = booster.run1_call(call)
+            r = runner.run1_call(call)
             t[v].append(time.perf_counter() - t0)
         for v in (a, b2):
             print(f"block {block}: {name}={v}: tick median {np.median(t[v][5:]) * 1e3:.3f} ms, p95 {np.percentile(t[v][5:], 95) * 1e3:.3f} ms")
@@ -50,7 +64,7 @@ def main():
     ticks = []
     for _ in range(args.ticks):
         t0 = time.perf_counter()
-        r = booster.run1_call(call)
+        r = runner.run1_call(call)
         ticks.append(time.perf_counter() - t0)
     print(f"block {block}: levels {int(r['k1'])}..{int(r['k2'])}, tick median {np.median(ticks[5:]) * 1e3:.3f} ms, "
           f"p95 {np.percentile(ticks[5:], 95) * 1e3:.3f} ms over {args.ticks - 5} ticks")
