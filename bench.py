@@ -297,7 +297,7 @@ def run1_host(booster):
     tick to tick, pageable and with ohx_register_host (registered once, then moved by one copy launch).  The same for
     P ranks sharing the GPU and for a C360/8 block: tools/ranks_per_gpu.py, profiles/r04_ranks_per_gpu*.json."""
     from quickchem_amd import synth
-    out = {"what": "OHXBoosterRun1 host form, steady-state tick (median of 20 after 3), one process", "blocks": []}
+    out = {"what": "OHXBoosterRun1 host form (and the fused predict-only call, host form), steady-state tick (median of 20 after 3), one process", "blocks": []}
     for block in ((48, 24, 72), (96, 48, 72)):
         st = synth.run1_state(block, seed=5)
         call = booster.run1_prepare(st, dynamic_k_range=True)
@@ -317,6 +317,18 @@ def run1_host(booster):
                 entry["levels_predicted"] = int(r["k2"] - r["k1"] + 1)
             elif not np.array_equal(ref.view(np.uint32), r["oh"].view(np.uint32)):
                 raise SystemExit("bench: OHXBoosterRun1 on registered arrays differs from the pageable run")
+        # ... and the fused predict-only call (OHXBoosterPredictFields: 27 fields in, OH_ML out, all levels), host form
+        im, jm, km = block
+        fields = [np.ascontiguousarray(synth.field_cpu(block, f).T) for f in range(synth.NFEAT)]
+        oh = np.zeros((km, jm, im), dtype=np.float32)
+        for mode, key in (("0", "fused_call_pageable_ms"), ("1", "fused_call_registered_ms")):
+            booster.set_param("ohx_register_host", mode)
+            ticks = []
+            for _ in range(23):
+                t0 = time.perf_counter()
+                booster.predict_fields(fields, synth.IS2D, synth.PL_FEATURE, im, jm, km, 1, km, synth.XX_MISS, oh, ohscale=0.85)
+                ticks.append(time.perf_counter() - t0)
+            entry[key] = float(np.median(ticks[3:])) * 1e3
         out["blocks"].append(entry)
     booster.set_param("ohx_register_host", "0")
     booster.lib.OHXReleaseScratch()
