@@ -101,6 +101,11 @@ module ESMF
    type, public :: ESMF_State
       type(esmfl_state_impl), pointer :: p => null()
    end type
+   !  a handle on one field of a state: the reference's OH Initialize declares two and never uses them
+   !  (OH_GridCompMod.F90:839; its ESMF_StateGet / ESMF_AttributeSet calls are comments, :912-919)
+   type, public :: ESMF_Field
+      type(esmfl_field), pointer :: p => null()
+   end type
 
    ! ------------------------------------------------------------------ grid components
    type, public :: ESMF_GridComp

@@ -12,6 +12,7 @@ module oh_run1
    private
 
    public :: OH_RUN1_STATE, OH_RUN1_DIAG, oh_run1_boost, oh_post_process, oh_solar_geometry, oh_julian_day
+   public :: oh_solar_geometry_host
    public :: oh_run1_error_text, oh_run1_register_host_arrays
 
    !  struct OHXRun1Args, member for member
@@ -121,6 +122,35 @@ contains
          last_error = 'Failed in OHXSolarGeometry :: '//ohx_last_error()
          rc = OH_XGB_FAILURE
       end if
+   end subroutine
+
+   !  The same two fields with the HOST's libm, as the reference computes them (:427-462, 1444): the zenith angle feeds
+   !  tree splits, so a run that must give the OH of a CPU run of the same executable takes its sines and cosines from
+   !  the same library.  A 2-D field once per Boost tick: microseconds.  The OH shell's default (solar_geometry: host).
+   subroutine oh_solar_geometry_host(jday, LATS, LONS, degrees_to_radians, radians_to_degrees, latarr, sza_noon)
+      integer, intent(in) :: jday
+      real, intent(in)  :: LATS(:,:), LONS(:,:)
+      real, intent(in)  :: degrees_to_radians, radians_to_degrees
+      real, intent(out) :: latarr(:,:), sza_noon(:,:)
+      real :: sindec, cosdec, sinlat, coslat, mylon, tau, loct, cosz
+      integer :: i, j
+      sindec = 0.3978 * sin(0.9863 * (jday - 80.0) * degrees_to_radians)
+      cosdec = cos(asin(sindec))
+      do j = 1, size(LATS, 2)
+         do i = 1, size(LATS, 1)
+            latarr(i,j) = LATS(i,j) * radians_to_degrees
+            sinlat = sin(LATS(i,j))
+            coslat = cos(asin(sinlat))
+            mylon = LONS(i,j) * radians_to_degrees                 ! local noon: the hour at which the sun is overhead here
+            if (mylon > 180.0) mylon = mylon - 360.0
+            if (mylon < -180.0) mylon = mylon + 360.0
+            tau = 12.0 + (mylon / (-180.0)) * 12.0
+            loct = ((tau * 15.0) - 180.0) * degrees_to_radians + LONS(i,j)
+            cosz = cosdec * coslat * cos(loct) + sindec * sinlat
+            cosz = max(-1.0, min(1.0, cosz))
+            sza_noon(i,j) = acos(cosz) * radians_to_degrees
+         end do
+      end do
    end subroutine
 
    !  Address of a field for the C side, or NULL with an error text: the library reads n1*n2*n3 floats from

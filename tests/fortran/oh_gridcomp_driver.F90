@@ -2,7 +2,9 @@
 !  through OH_GridComp Run".  SetServices of the parent (which creates the OH instances), Initialize, then
 !  `nticks` heartbeats of Run phase 1, Run phase 2 and clock advance, through the ESMF / MAPL calls a cap makes, served by
 !  the mock in quickchem_amd/fortran/mapl_lite/ (no MAPL, no ESMF here).  The parent, QuickChem_GridCompMod, is the
-!  reference's own unmodified file, compiled in place by oracle/Makefile (target `ref`); the child is the product's.  Being the mock's cap it also plays "the rest of GEOS": storage for
+!  reference's own unmodified file, compiled in place by oracle/Makefile (target `ref`); the child is the product's -
+!  or, built with -DOHX_REFERENCE_CHILD, the reference's own OH_GridComp/OH_GridCompMod.F90, also compiled in place (the
+!  drivers oracle/_ref/refchild/oh_refchild_driver_*: the reference's lines as the checker of the product's).  Being the mock's cap it also plays "the rest of GEOS": storage for
 !  the imports, HISTORY's wish list of exports, the model moving between heartbeats (esmfl_ / mapll_ calls).
 !
 !  usage: oh_gridcomp_driver <run dir> <state.bin> <out.bin> <nticks>
@@ -30,7 +32,9 @@ program oh_gridcomp_driver
    use ESMF
    use MAPL
    use QuickChem_GridCompMod, only: QuickChem_SetServices => SetServices, IS_QC_INSTANCE_RUNNING
+#ifndef OHX_REFERENCE_CHILD
    use OH_GridCompMod, only: oh_last_run
+#endif
    implicit none
 
    character(len=ESMF_MAXPATHLEN) :: rundir, state_file, out_file, arg, model_file, spec_file
@@ -189,9 +193,15 @@ program oh_gridcomp_driver
             cycle
          end if
          call MAPL_GetPointer(internal, oh, 'OH', rc=rc)
+#ifdef OHX_REFERENCE_CHILD
+         !  the reference's child says nothing about its last tick: -1 = not known (the test works it out)
+         write(uo) -1_c_int32_t, -1_c_int32_t, -1_c_int32_t, -1_c_int32_t
+         model_file = ''
+#else
          call oh_last_run(gcs(c), ran, boosted, model_file, k1, k2)
          write(uo) merge(1_c_int32_t, 0_c_int32_t, ran), merge(1_c_int32_t, 0_c_int32_t, boosted), &
                    int(k1, c_int32_t), int(k2, c_int32_t)
+#endif
          write(uo) model_file(1:256)
          write(uo) oh
          !  what GEOS_ChemGridComp's other children would connect to: the parent's export OH
