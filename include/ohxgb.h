@@ -176,7 +176,8 @@ int OHXDMatrixInferGrid(DMatrixHandle handle, void* stream, int* found);
  * leaf ids with option_mask 16).  `stream` is a hipStream_t (NULL = default
  * stream); the call only enqueues work (but see OHXDMatrixInferGrid for the first
  * predict on an undescribed matrix).  OHXBoosterCheck surfaces errors the
- * kernels raised (inf in the input).  A booster keeps single scratch buffers
+ * kernels raised (inf in the input; without it a device form's caller never
+ * learns of them).  A booster keeps single scratch buffers
  * (error flags, Run1 intermediates, staging): calls on ONE booster must not run
  * concurrently on two streams or threads; different boosters are independent. */
 int OHXBoosterPredictDevice(BoosterHandle handle, DMatrixHandle dmat, int option_mask, unsigned ntree_limit,
@@ -289,6 +290,20 @@ int OHXBoosterGetInfo(BoosterHandle handle, bst_ulong info[8]);
  * booster's current parameters, as a profiler prints it (without namespaces and arguments), e.g.
  * "predict_rows_tile_kernel<2,2,true,true>".  *out stays valid until the next call on this handle. */
 int OHXBoosterKernelSymbol(BoosterHandle handle, bst_ulong ncol, const char** out);
+/* Every GPU kernel a margin predict on THIS matrix launches with the booster's current parameters, in launch order,
+ * joined by " + " - the size of the batch decides (a small one has its trees split over waves and a second launch that
+ * sums the leaves in tree order; a big one of the OH booster goes through the ring kernel and the launches behind it).
+ * Decided by the code that launches (kernels.hip plan_rows).  Not listed: the clustering pass in front of rows that
+ * are in no known order, the level-size search of a matrix nobody described.  *out as above. */
+int OHXBoosterKernelSymbolRows(BoosterHandle handle, DMatrixHandle dmat, const char** out);
+/* How often a block of the ring kernels (the default for the OH booster's big batches) gave up waiting for another
+ * since the booster's forest went to the GPU.  Never seen in 6 700 whole-batch calls (tools/ring_soak.py), and not an
+ * error: every ring launch train is followed, on the same stream, by a launch of the tile kernel that only runs when a
+ * block gave up and then predicts the train's rows again - same bits, the host is not involved, so the device forms
+ * (OHXBoosterPredictDevice, ...FieldsDevice, Run1Device) are covered without OHXBoosterCheck.  The first sighting is
+ * said on stderr by the next call that reads the flags back.  Waits for `stream`.  (The reference asserts rc == 0 on
+ * XGBoosterPredict, OH_GridComp/OH_GridCompMod.F90:356-358: a time-out must not end a model run.) */
+int OHXBoosterRingReruns(BoosterHandle handle, void* stream, bst_ulong* out);
 
 /* ------------------------------------------------------------------------
  * Part 4 — reassembling the OH field across the GPUs of a node (additive)

@@ -28,7 +28,8 @@ ABI_SYMBOLS = [
     "XGBoosterSaveModel", "XGBoosterLoadModelFromBuffer", "XGBoosterPredict", "XGBoosterSetParam",
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXDMatrixInferGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device", "OHXOHPostProcess", "OHXOHPostProcessDevice",
-    "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXBoosterKernelSymbol", "OHXReleaseScratch",
+    "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXBoosterKernelSymbol", "OHXBoosterKernelSymbolRows",
+    "OHXBoosterRingReruns", "OHXReleaseScratch",
     "OHXCommGetUniqueId", "OHXCommInitRank", "OHXCommFree", "OHXCommInfo", "OHXShardRows", "OHXAllGatherOH",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
@@ -121,6 +122,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.OHXSolarGeometryDevice.argtypes = [i32, vp, vp, i32, i32, f32, f32, vp, vp, vp]
     lib.OHXBoosterGetInfo.argtypes = [vp, C.POINTER(u64)]
     lib.OHXBoosterKernelSymbol.argtypes = [vp, u64, C.POINTER(C.c_char_p)]
+    lib.OHXBoosterKernelSymbolRows.argtypes = [vp, vp, C.POINTER(C.c_char_p)]
+    lib.OHXBoosterRingReruns.argtypes = [vp, vp, C.POINTER(u64)]
     lib.OHXReleaseScratch.argtypes = []
     lib.OHXCommGetUniqueId.argtypes = [vp]
     lib.OHXCommInitRank.argtypes = [vp, i32, i32, C.POINTER(vp)]
@@ -374,9 +377,21 @@ class Booster:
                 "gathers_per_wave"]
         return {k: int(arr[i]) for i, k in enumerate(keys)}
 
+    def ring_reruns(self, stream: int = 0) -> int:
+        """How often a ring block gave up and the tile kernel predicted the batch again (include/ohxgb.h)."""
+        out = C.c_uint64()
+        check(self.lib, self.lib.OHXBoosterRingReruns(self.handle, stream, C.byref(out)))
+        return int(out.value)
+
     def kernel_symbol(self, ncol: int) -> str:
         out = C.c_char_p()
         check(self.lib, self.lib.OHXBoosterKernelSymbol(self.handle, ncol, C.byref(out)))
+        return out.value.decode()
+
+    def kernel_symbols_for(self, dmat) -> str:
+        """Every kernel a margin predict on `dmat` launches, in order, joined by " + " (OHXBoosterKernelSymbolRows)."""
+        out = C.c_char_p()
+        check(self.lib, self.lib.OHXBoosterKernelSymbolRows(self.handle, dmat.handle, C.byref(out)))
         return out.value.decode()
 
     def fields_kernel_symbol(self, nrow: int = 1 << 30) -> str:

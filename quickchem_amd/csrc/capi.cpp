@@ -422,6 +422,7 @@ struct BoosterObj {
   std::string symbol;                   // OHXBoosterKernelSymbol's answer
   DevBuf<uint32_t> d_roots;
   DevBuf<uint32_t> d_flags;
+  uint32_t ring_reruns_seen = 0;        // of d_flags[1], as last read back; the first sighting is said on stderr
   DevBuf<float> d_leaves;               // small batches (kernels.hpp PredictArgs::leaf_buf): [tile][tree][lane] leaf values
   DevBuf<uint32_t> d_defer;             // deferred rows (kernels.hpp PredictArgs::defer_list): the count, then the list
   // how many rows of the last batch held missing values (read back behind the batch, looked at before the next one)
@@ -558,8 +559,9 @@ void ensure_uploaded(BoosterObj& b) {
     b.d_packed.upload(packed);
   }
   if (pick_kernel(b) == KernelKind::Wide) ensure_wide(b);
-  b.d_flags.ensure(1);
-  HIP_CHECK(hipMemset(b.d_flags.p, 0, sizeof(uint32_t)));
+  b.d_flags.ensure(2);      // [0] kFlag* bits, [1] ring re-runs counted on the device (kernels.hip ring_settle_kernel)
+  HIP_CHECK(hipMemset(b.d_flags.p, 0, 2 * sizeof(uint32_t)));
+  b.ring_reruns_seen = 0;
   if (!b.train.side) {
     HIP_CHECK(hipStreamCreateWithFlags(&b.train.side, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&b.train.fork, hipEventDisableTiming));
@@ -616,14 +618,23 @@ void check_columns(const BoosterObj& b, uint64_t ncol) {
 }
 
 void raise_flag_errors(BoosterObj& b, hipStream_t stream) {
-  uint32_t flags = 0;
-  HIP_CHECK(hipMemcpyAsync(&flags, b.d_flags.p, sizeof(flags), hipMemcpyDeviceToHost, stream));
+  uint32_t flags[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(flags, b.d_flags.p, sizeof(flags), hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
-  if (flags != 0) {
+  // a ring block that timed out is not an error: its rows were walked again by the tile kernel on the stream, behind
+  // the train (kernels.hip launch_rows_ring); worth a line on stderr the first time, and a counter from then on
+  if (flags[1] != b.ring_reruns_seen) {
+    if (b.ring_reruns_seen == 0)
+      fprintf(stderr, "[libohxgb] warning: a block of the ring kernel gave up waiting for another; the batch was predicted "
+                      "again by the tile kernel (same results, slower).  Counted in OHXBoosterRingReruns; "
+                      "ohx_kernel=super2 avoids the ring kernels.\n");
+    b.ring_reruns_seen = flags[1];
+  }
+  if (flags[0] != 0) {
     HIP_CHECK(hipMemsetAsync(b.d_flags.p, 0, sizeof(uint32_t), stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (flags & kFlagInfInput) throw OhxError("Input data contains `inf` or `nan`");
-    throw OhxError("the predict kernel reported error flags " + std::to_string(flags));
+    if (flags[0] & kFlagInfInput) throw OhxError("Input data contains `inf` or `nan`");
+    throw OhxError("the predict kernel reported error flags " + std::to_string(flags[0]));
   }
 }
 
@@ -840,7 +851,7 @@ void leaf_room(BoosterObj& b, uint64_t nrow, uint32_t ntree, LaunchTuning& tune,
   tune.leaf_words = b.d_leaves.n;
 }
 
-bool defer_prepare(BoosterObj& b, uint64_t nrow, LaunchTuning& tune) {
+bool defer_prepare(BoosterObj& b, uint64_t nrow, LaunchTuning& tune, hipStream_t stream) {
   if (tune.defer_missing == 0 || !(tune.defer_missing > 0 || nrow >= (1u << 18))) return false;
   if (b.defer_pending && hipEventQuery(b.defer_seen) == hipSuccess) {
     b.defer_pending = false;
@@ -850,7 +861,9 @@ bool defer_prepare(BoosterObj& b, uint64_t nrow, LaunchTuning& tune) {
   b.d_defer.ensure((size_t)(nrow / 32 + 1024 + 1));
   // the launchers zero the count only when they really defer (kernels.hip launch_predict: prefetch kernel, no split
   // ...); defer_look reads it back regardless, so a buffer fresh from hipMalloc must not hold garbage
-  if (b.d_defer.p != before) HIP_CHECK(hipMemset(b.d_defer.p, 0, sizeof(uint32_t)));
+  // on the stream the launches and defer_look's read-back run on: those streams are non-blocking, a NULL-stream memset
+  // is not ordered before them
+  if (b.d_defer.p != before) HIP_CHECK(hipMemsetAsync(b.d_defer.p, 0, sizeof(uint32_t), stream));
   tune.defer_buf = b.d_defer.p;
   tune.defer_words = b.d_defer.n;
   tune.defer_count_only = (b.defer_too_many && tune.defer_missing < 0) ? 1 : 0;
@@ -898,7 +911,7 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
   a.perm = cluster_rows(b, d, a, pred_leaf, kind, stream);
   if (!pred_leaf && a.perm == nullptr) leaf_room(b, d.nrow, a.tree_end - a.tree_begin, tune, tune.grid_im, tune.grid_jm, tune.grid_row0);
   // rows with missing values leave for a second, small launch instead of slowing their whole wave down (big batches)
-  const bool deferring = a.perm == nullptr && !pred_leaf && d.ncol == 27 && defer_prepare(b, d.nrow, tune);
+  const bool deferring = a.perm == nullptr && !pred_leaf && d.ncol == 27 && defer_prepare(b, d.nrow, tune, stream);
   HIP_CHECK(launch_predict(kind, device_forest(b), a, b.dev.num_cus, stream, tune));
   if (deferring) defer_look(b, d.nrow, stream);
   if (a.perm != nullptr) {
@@ -1225,17 +1238,20 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     g_host_registry.on.store(atoi(value) != 0);
     if (atoi(value) == 0) g_host_registry.release_all();
   } else if (n == "ohx_reserve_cus") {
-    b->tune.reserve_cus = atoi(value);
-    if (b->tune.reserve_cus < 0 || b->tune.reserve_cus > 128) throw OhxError("ohx_reserve_cus must be 0..128");
+    const int k = atoi(value);
+    if (k < 0 || k > 128) throw OhxError("ohx_reserve_cus must be 0..128");
+    b->tune.reserve_cus = k;
   } else if (n == "ohx_ring_rounds") {
-    b->tune.ring_rounds = atoi(value);
-    if (b->tune.ring_rounds < 0) throw OhxError("ohx_ring_rounds must be >= 0");
+    const int k = atoi(value);
+    if (k < 0) throw OhxError("ohx_ring_rounds must be >= 0");
+    b->tune.ring_rounds = k;
   } else if (n == "ohx_tree_split") {
     if (v == "auto") b->tune.tree_split = -1;
     else if (v == "off") b->tune.tree_split = 0;
     else {
-      b->tune.tree_split = atoi(value);
-      if (b->tune.tree_split < 2 || b->tune.tree_split > 10) throw OhxError("ohx_tree_split must be auto, off or 2..10");
+      const int k = atoi(value);
+      if (k < 2 || k > 10) throw OhxError("ohx_tree_split must be auto, off or 2..10");
+      b->tune.tree_split = k;
     }
   } else if (n == "ohx_defer_missing") {
     if (v != "auto" && v != "on" && v != "off") throw OhxError("ohx_defer_missing must be auto, on or off");
@@ -1247,8 +1263,9 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
   } else if (n == "ohx_xcd_remap") {
     b->tune.xcd_remap = atoi(value) != 0;
   } else if (n == "ohx_overlap_group") {
-    b->tune.overlap_group = atoi(value);
-    if (b->tune.overlap_group < 0) throw OhxError("ohx_overlap_group must be >= 0");
+    const int k = atoi(value);
+    if (k < 0) throw OhxError("ohx_overlap_group must be >= 0");
+    b->tune.overlap_group = k;
   } else if (n == "ohx_tree_tops") {
     const std::string v = value;
     if (v != "auto" && v != "on" && v != "off") throw OhxError("ohx_tree_tops must be auto, on or off");
@@ -1352,7 +1369,7 @@ int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fie
     const uint64_t nrow = (uint64_t)im * (uint64_t)jm * (uint64_t)(a.k2 - a.k1 + 1);
     LaunchTuning tune = b->tune;
     leaf_room(*b, nrow, a.tree_end - a.tree_begin, tune, im, jm, 0);
-    const bool deferring = nfield == 27 && defer_prepare(*b, nrow, tune);
+    const bool deferring = nfield == 27 && defer_prepare(*b, nrow, tune, static_cast<hipStream_t>(stream));
     HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus,
                                     static_cast<hipStream_t>(stream), tune));
     if (deferring) defer_look(*b, nrow, static_cast<hipStream_t>(stream));
@@ -1440,7 +1457,7 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
     LaunchTuning tune = b->tune;
     const uint64_t piece_rows = plane * (l1 - l0);
     leaf_room(*b, piece_rows, piece.tree_end - piece.tree_begin, tune, im, jm, 0);
-    const bool deferring = nfield == 27 && defer_prepare(*b, piece_rows, tune);
+    const bool deferring = nfield == 27 && defer_prepare(*b, piece_rows, tune, b->s_exec);
     HIP_CHECK(launch_predict_fields(pick_kernel(*b), device_forest(*b), piece, b->dev.num_cus, b->s_exec, tune));
     if (deferring) defer_look(*b, piece_rows, b->s_exec);
   }
@@ -1540,7 +1557,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
     const uint64_t slab_rows = plane * (uint64_t)(k2 - k1 + 1);
     LaunchTuning tune = b.tune;
     leaf_room(b, slab_rows, fa.tree_end - fa.tree_begin, tune, r.im, r.jm, 0);
-    const bool deferring = defer_prepare(b, slab_rows, tune);
+    const bool deferring = defer_prepare(b, slab_rows, tune, stream);
     HIP_CHECK(launch_predict_fields(pick_kernel(b), device_forest(b), fa, b.dev.num_cus, stream, tune));
     if (deferring) defer_look(b, slab_rows, stream);
   }
@@ -1594,7 +1611,7 @@ struct PostScratch {
   int device = -1;
   DevBuf<float> buf[8];
 };
-PostScratch g_post;
+static PostScratch g_post;   // static: inside extern "C" an unnamed namespace alone does not keep the name out of the dynamic table
 }  // namespace
 
 int OHXOHPostProcess(int im, int jm, int km, float avogad, float runiv, float epsilon, const float* ple_mod,
@@ -1815,6 +1832,44 @@ int OHXBoosterKernelSymbol(BoosterHandle handle, bst_ulong ncol, const char** ou
   ensure_uploaded(*b);
   b->symbol = predict_kernel_symbol(pick_kernel(*b), device_forest(*b), (uint32_t)ncol, b->tune);
   *out = b->symbol.c_str();
+  API_END();
+}
+
+int OHXBoosterKernelSymbolRows(BoosterHandle handle, DMatrixHandle dmat, const char** out) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  DMatrixObj* d = as_dmat(dmat);
+  if (out == nullptr) throw OhxError("OHXBoosterKernelSymbolRows: out is NULL");
+  check_columns(*b, d->ncol);
+  ensure_uploaded(*b);
+  PredictArgs a;
+  a.rows = d->d_data;
+  a.nrow = d->nrow;
+  a.ncol = (uint32_t)d->ncol;
+  a.missing = d->missing;
+  tree_range(*b, 0, &a.tree_begin, &a.tree_end);
+  LaunchTuning tune = b->tune;
+  tune.grid_im = d->grid_im;
+  tune.grid_jm = d->grid_jm;
+  tune.grid_row0 = d->grid_row0;
+  leaf_room(*b, d->nrow, a.tree_end - a.tree_begin, tune, tune.grid_im, tune.grid_jm, tune.grid_row0);
+  if (d->ncol == 27) (void)defer_prepare(*b, d->nrow, tune, nullptr);
+  b->symbol = predict_kernel_symbols_rows(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus, tune);
+  *out = b->symbol.c_str();
+  API_END();
+}
+
+int OHXBoosterRingReruns(BoosterHandle handle, void* stream, bst_ulong* out) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  if (out == nullptr) throw OhxError("OHXBoosterRingReruns: out is NULL");
+  *out = 0;
+  if (b->uploaded) {
+    uint32_t n = 0;
+    HIP_CHECK(hipMemcpyAsync(&n, b->d_flags.p + 1, sizeof(n), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    *out = n;
+  }
   API_END();
 }
 

@@ -705,6 +705,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   // noalias: with the margins' stores provably elsewhere, the wave-uniform head records stay scalar
   // loads (as members of the by-value structs they turn into one more vector load per walk)
   extern __shared__ float lds[];
+  // the launch behind a ring train (launch_rows_ring): nothing to do unless a ring block gave up
+  if (a.only_if_flag != 0u &&
+      (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & a.only_if_flag) == 0u)
+    return;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   // the waves' feature tiles first, the first-step table behind them (see tile_lds_bytes)
@@ -864,7 +868,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
 // everybody else and publishes g + 1 from inside that walk, behind the LDS steps, when its DMA has had their time to
 // land.  Nobody waits for anybody unless it is two groups ahead of the slowest wave or its next group has not landed.
 // Every wait is on work with a lower group number, so the waves cannot wait in a circle; the spins are bounded all the
-// same and a wave that gives up raises kFlagRingTimeout (the host turns it into an error).
+// same.  A wave that gives up says so in a fourth word, `abort`, which every spinning wave of the block reads: from then
+// on nobody in the block waits, stages, walks or stores - the block runs through its rounds in no time, raises
+// kFlagRingTimeout, and the launch the launcher put behind the train (the tile kernel, predicated on that bit) walks
+// the train's rows instead.  (Until round 4 a time-out was an error: rc -1 into the caller's _ASSERT,
+// OH_GridCompMod.F90:358; and the waves that had not given up themselves spun on, limit after limit.)
 //
 // C360 step: 27.4 ms against the tile kernel's 31.1, and 24.3 with issue priorities (ring_walk_group); with them the ring
 // wins from 5 steps per tree on (depth 10: 13.8 against 14.2 ms; depth 8: 12.0 against 11.8), which is where the host
@@ -879,7 +887,10 @@ constexpr uint32_t kRingTreeBytes = kRingSlots * 16u;
 constexpr uint32_t kRingBufBytes = kRingChains * kRingTreeBytes;        // 11 264
 constexpr uint32_t kRingDmaLoads = kRingChains * kRingSlots / kWave;    // 11 wave instructions per group
 static_assert(kRingChains * kRingSlots % kWave == 0, "a group is whole wave loads");
-constexpr uint32_t kRingSpinLimit = 1u << 21;
+#ifndef OHX_EXP_RING_SPIN
+#define OHX_EXP_RING_SPIN (1u << 21)      // scratch builds set it to 1 to see what a time-out does (tests/test_gpu_parity.py)
+#endif
+constexpr uint32_t kRingSpinLimit = OHX_EXP_RING_SPIN;
 constexpr size_t kRingLdsBytes = (size_t)kRingWaves * 27 * kWave * sizeof(float) + (size_t)kRingBuffers * kRingBufBytes +
                                  (size_t)(kRingWaves + 4) * sizeof(uint32_t);
 static_assert(kRingLdsBytes <= 160 * 1024, "LDS of a block");
@@ -900,10 +911,13 @@ __device__ __forceinline__ void ring_order() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ void dma_to_lds_b128(u32x4 desc, uint32_t off, uint32_t lds_addr) {
 #if defined(__gfx950__)
   uint32_t keep;
+  // (the LDS address is the same in every lane; said so explicitly: where hipcc's divergence analysis loses track of
+  // that - the staging now sits behind "has the block aborted?" - it would hand M0 a vector register)
+  const uint32_t m0_value = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(off), "s"(desc), "s"(lds_addr)
+      : "v"(off), "s"(desc), "s"(m0_value)
       : "memory");
 #else
   // 16-byte LDS-DMA is a gfx950 instruction; this library is built for nothing else (a sanitizer build of the HOST
@@ -917,7 +931,7 @@ __device__ __forceinline__ void dma_to_lds_b128(u32x4 desc, uint32_t off, uint32
 struct TopRing {
   lds_cptr ring;              // [kRingBuffers][kRingChains][kRingSlots] records
   uint32_t ring_addr;         // the same as an LDS byte address (for the DMA's M0)
-  lds_u32_ptr progress, filled, claim;
+  lds_u32_ptr progress, filled, claim, abort;
   u32x4 desc;                 // buffer descriptor over the forest's super-nodes
   __amdgpu_buffer_rsrc_t forest;
   const SuperTreeHead* heads;
@@ -952,6 +966,7 @@ __device__ __forceinline__ void ring_begin(TopRing& rg, char* ring, const Device
   rg.progress = (lds_u32_ptr)(ring + (size_t)kRingBuffers * kRingBufBytes);
   rg.filled = rg.progress + kRingWaves;
   rg.claim = rg.progress + kRingWaves + 1;
+  rg.abort = rg.progress + kRingWaves + 2;
   const uint64_t addr = reinterpret_cast<uint64_t>(fr.super);
   rg.desc.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);
   rg.desc.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(addr >> 32) & 0xFFFFu));
@@ -973,6 +988,7 @@ __device__ __forceinline__ void ring_begin(TopRing& rg, char* ring, const Device
   if (threadIdx.x == 0) {
     ring_store(rg.filled, 1u);
     ring_store(rg.claim, 1u);
+    ring_store(rg.abort, 0u);
   }
   __syncthreads();
 }
@@ -1040,10 +1056,22 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
   return acc;
 }
 
+// has a wave of the block given up?  (wave-uniform: what the answer guards - staging through M0 - must stay scalar)
+__device__ __forceinline__ bool ring_aborted(const TopRing& rg) {
+  return __builtin_amdgcn_readfirstlane((int)ring_load(rg.abort)) != 0;
+}
+
+// This wave stops waiting, and tells the block.
+__device__ __forceinline__ void ring_give_up(TopRing& rg, int lane) {
+  rg.gave_up = true;
+  if (lane == 0) ring_store(rg.abort, 1u);
+}
+
 // All trees of the launch for the wave's tile (live: the wave has one; a wave without still goes round: the others
 // count on its progress).  `last_round`: nothing is staged behind the last group of the block's last round.
 __device__ __forceinline__ float ring_walk_tile(TopRing& rg, float acc, const float* __restrict__ tile, bool live,
                                                 bool wave_nan, int lane, int wave) {
+  if (rg.gave_up) return acc;           // (the block's other waves see `abort` at their next wait)
   for (uint32_t p = 0; p < rg.ngroups; ++p, ++rg.g) {
     const uint32_t g = rg.g;
     const uint32_t t = rg.t0 + p * kRingChains;
@@ -1070,17 +1098,18 @@ __device__ __forceinline__ float ring_walk_tile(TopRing& rg, float acc, const fl
       uint32_t spin = 0;
       while (!__all(lane >= kRingWaves || ring_load(rg.progress + (lane < kRingWaves ? lane : 0)) >= need)) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spin > kRingSpinLimit) { rg.gave_up = true; break; }
+        if (++spin > kRingSpinLimit || ring_aborted(rg)) { ring_give_up(rg, lane); break; }
       }
       ring_order();
-      ring_stage(rg, (p + 1 == rg.ngroups) ? rg.t0 : t + kRingChains, (g + 1u) % kRingBuffers, lane);
+      // a wave that gave up must not write over a buffer the others may still be reading
+      if (!rg.gave_up) ring_stage(rg, (p + 1 == rg.ngroups) ? rg.t0 : t + kRingChains, (g + 1u) % kRingBuffers, lane);
     }
     // ---- group g complete in the ring?
-    if (filled_now < g + 1u) {
+    if (filled_now < g + 1u && !rg.gave_up) {
       uint32_t spin = 0;
-      while (ring_load(rg.filled) < g + 1u) {
+      while ((uint32_t)__builtin_amdgcn_readfirstlane((int)ring_load(rg.filled)) < g + 1u) {      // (uniform: see ring_aborted)
         __builtin_amdgcn_s_sleep(1);
-        if (++spin > kRingSpinLimit) { rg.gave_up = true; break; }
+        if (++spin > kRingSpinLimit || ring_aborted(rg)) { ring_give_up(rg, lane); break; }
       }
     }
     ring_order();       // the buffer is read after `filled` said so, not before
@@ -1096,7 +1125,7 @@ __device__ __forceinline__ float ring_walk_tile(TopRing& rg, float acc, const fl
                      : ring_walk_group<false>(h, here, rg.forest, tile, buf, acc, pub, g + 2u, won != 0u);
     } else if (won) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // a stager without a tile
-      if (lane == 0) ring_store(rg.filled, g + 2u);
+      if (lane == 0 && !rg.gave_up) ring_store(rg.filled, g + 2u);
     }
     ring_order();                                             // the walk's reads of the buffer are done
     if (lane == 0) ring_store(rg.progress + wave, g + 1u);
@@ -1243,6 +1272,14 @@ __global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4)))
   if (rg.gave_up && a.flags) atomicOr(a.flags, kFlagRingTimeout);
 }
 
+// Behind a ring train and its predicated tile launch: a time-out is over - the bit goes, the event is counted.
+__global__ void ring_settle_kernel(uint32_t* __restrict__ flags) {
+  if (threadIdx.x == 0 && (flags[0] & kFlagRingTimeout) != 0u) {
+    atomicAnd(flags, ~(uint32_t)kFlagRingTimeout);
+    atomicAdd(flags + 1, 1u);
+  }
+}
+
 // The second launch of a small batch (PredictArgs::leaf_buf): one wave per tile, margin = ((base + leaf_0) + leaf_1) + ...
 __global__ __launch_bounds__(kBlock) void combine_leaves_kernel(PredictArgs a, float base_score, float* __restrict__ out) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -1303,6 +1340,9 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
                                                                 float* __restrict__ out,
                                                                 float* __restrict__ margin_out) {
   extern __shared__ float lds[];
+  if (a.only_if_flag != 0u &&       // the launch behind a ring train: nothing to do unless a ring block gave up
+      (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & a.only_if_flag) == 0u)
+    return;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   float* tile = lds + (size_t)wave * fr.num_feature * kWave + lane;
@@ -1972,6 +2012,26 @@ hipError_t launch_rows_ring(const DeviceForest& fr, PredictArgs a, int num_cus, 
   }
   e = train.meet();
   if (e != hipSuccess) return e;
+  // A ring block that gave up waiting (kFlagRingTimeout) has not written its rows.  Behind the train: the tile kernel
+  // over ALL of the train's rows, every block of which leaves at once unless that bit is set (5 us per step when it
+  // is not), missing-aware and without deferring; then the bit is cleared and the event counted.  Stream-ordered, so
+  // the device forms need no host in the loop (include/ohxgb.h: OHXBoosterGetInfo "ring_reruns").
+  if (a.flags != nullptr) {
+    auto again = predict_rows_tile_kernel<2, 2, true, true>;
+    const size_t lds2 = tile_lds_bytes(fr.num_feature, true);
+    e = ensure_lds(again, lds2);
+    if (e != hipSuccess) return e;
+    PredictArgs b = a;
+    b.only_if_flag = kFlagRingTimeout;
+    b.defer_list = nullptr;
+    b.defer_count = nullptr;
+    b.defer_cap = 0;
+    b.tile_begin = 0;
+    b.tile_end = ntiles;
+    hipLaunchKernelGGL(again, dim3(tile_grid(again, lds2, ntiles, num_cus)), dim3(kBlock), lds2, stream, fr, b, fr.super_heads,
+                       b.out);
+    hipLaunchKernelGGL(ring_settle_kernel, dim3(1), dim3(kWave), 0, stream, a.flags);
+  }
   return hipGetLastError();
 }
 
@@ -2013,43 +2073,41 @@ const char* kernel_kind_name(KernelKind k) {
   return "?";
 }
 
-hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const PredictArgs& a_in, int num_cus,
-                          hipStream_t stream, const LaunchTuning& tune) {
-  if (a_in.nrow == 0) return hipSuccess;
-  PredictArgs a = a_in;
-  const bool is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
-                        kind == KernelKind::Super4 || kind == KernelKind::Ring;
-  const size_t lds = tile_lds_bytes(fr.num_feature, is_super);
-  const bool tile_ok = fr.num_feature >= 1 && lds <= 160 * 1024 && a.ncol <= fr.num_feature;
-  if (is_super && fr.super == nullptr) return hipErrorInvalidValue;
-  if (a.pred_leaf || kind == KernelKind::Wide || !tile_ok || (!is_super && fr.packed == nullptr)) {
-    if (fr.wide == nullptr) return hipErrorInvalidValue;
-    const int grid = grid_for(a.nrow, num_cus, 8);
-    if (a.pred_leaf) hipLaunchKernelGGL(predict_rows_direct_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, fr, a);
-    else hipLaunchKernelGGL(predict_rows_direct_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, fr, a);
-    return hipGetLastError();
+// What launch_predict does with a batch, decided in one place so that OHXBoosterKernelSymbolRows can say it too.
+struct RowsPlan {
+  bool ok = true;          // false: the forest has no array this kind of kernel could read
+  bool is_super = false;
+  bool direct = false;     // predict_rows_direct_kernel (wide nodes, no LDS)
+  bool pf = false;         // 27-column rows, the next tile's in flight during a walk
+  bool defer = false, listing = false;      // rows with missing values counted / left to a second launch
+  bool ring = false;       // predict_rows_ring_kernel
+  uint32_t split = 0;      // > 0: a small batch, its trees in this many runs over waves
+  TileShape split_shape;
+  size_t lds = 0;
+};
+
+RowsPlan plan_rows(KernelKind kind, const DeviceForest& fr, const PredictArgs& a, int num_cus, const LaunchTuning& tune) {
+  RowsPlan p;
+  p.is_super = kind == KernelKind::Super1 || kind == KernelKind::Super2 || kind == KernelKind::Super3 ||
+               kind == KernelKind::Super4 || kind == KernelKind::Ring;
+  p.lds = tile_lds_bytes(fr.num_feature, p.is_super);
+  const bool tile_ok = fr.num_feature >= 1 && p.lds <= 160 * 1024 && a.ncol <= fr.num_feature;
+  if (p.is_super && fr.super == nullptr) p.ok = false;
+  if (a.pred_leaf || kind == KernelKind::Wide || !tile_ok || (!p.is_super && fr.packed == nullptr)) {
+    p.direct = true;
+    return p;
   }
   // every wave gets more than one tile per launch and the rows are the OH shape: prefetch
-  const bool pf = a.ncol == 27 && fr.num_feature == 27 && tune.launches_per_residency != 1 && tune.prefetch;
+  p.pf = a.ncol == 27 && fr.num_feature == 27 && tune.launches_per_residency != 1 && tune.prefetch;
   // rows with missing values are left to a second launch (PredictArgs::defer_list)
   constexpr uint64_t kDeferMinRows = 1u << 18;
-  const bool defer = pf && a.perm == nullptr && tune.defer_buf != nullptr && tune.defer_words >= 2 && a.nrow < 0xFFFFFFF0ull &&
-                     (tune.defer_missing > 0 || (tune.defer_missing < 0 && a.nrow >= kDeferMinRows));
-  const bool listing = defer && !tune.defer_count_only;
-  if (defer) {
-    const uint64_t want = a.nrow / 32 + 1024;                                   // room for ~3 % of the rows
-    a.defer_cap = listing ? (uint32_t)(want < tune.defer_words - 1 ? want : tune.defer_words - 1) : 0u;
-    a.defer_count = tune.defer_buf;
-    a.defer_list = tune.defer_buf + 1;
-    hipError_t e = hipMemsetAsync(a.defer_count, 0, sizeof(uint32_t), stream);
-    if (e == hipSuccess && listing) e = hipMemsetAsync(a.defer_list, 0xFF, (size_t)a.defer_cap * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-  }
+  p.defer = p.pf && a.perm == nullptr && tune.defer_buf != nullptr && tune.defer_words >= 2 && a.nrow < 0xFFFFFFF0ull &&
+            (tune.defer_missing > 0 || (tune.defer_missing < 0 && a.nrow >= kDeferMinRows));
+  p.listing = p.defer && !tune.defer_count_only;
   // A small batch leaves most of the chip's wave slots empty and takes as long as one tile's walk of ALL trees
   // (165 us for the OH booster whatever N, profiles/r03_latency_rows.json): cut the trees into runs walked by
   // different waves.  Decided on the live tiles of the batch against the chip's 20 waves per CU.
-  uint32_t split = 0;
-  if (is_super && a.perm == nullptr && tune.tree_split != 0 && tune.leaf_buf != nullptr && a.tree_end - a.tree_begin >= 8) {
+  if (p.is_super && a.perm == nullptr && tune.tree_split != 0 && tune.leaf_buf != nullptr && a.tree_end - a.tree_begin >= 8) {
     PredictArgs probe = a;
     shape_rows(probe, tune);
     // bricks laid over a level of which the batch holds a small part are mostly empty: 64 consecutive rows per wave then
@@ -2062,10 +2120,43 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
     if (want > 10) want = 10;
     if (want * 4 > ntree) want = ntree / 4;
     if (want >= 2 && ntiles * ntree * kWave <= tune.leaf_words) {
-      split = (uint32_t)want;
-      a.shape = probe.shape;
+      p.split = (uint32_t)want;
+      p.split_shape = probe.shape;
     }
   }
+  // the ring kernel takes the OH shape with the next rows in flight (a big batch); everything else of a booster
+  // that asked for it - small batches with their trees split over waves, other column counts, the second launch of
+  // the deferred rows - goes the super2 way
+  p.ring = kind == KernelKind::Ring && p.pf && !p.split && a.tree_end > a.tree_begin;
+  return p;
+}
+
+hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const PredictArgs& a_in, int num_cus,
+                          hipStream_t stream, const LaunchTuning& tune) {
+  if (a_in.nrow == 0) return hipSuccess;
+  PredictArgs a = a_in;
+  const RowsPlan plan = plan_rows(kind, fr, a, num_cus, tune);
+  if (!plan.ok) return hipErrorInvalidValue;
+  const size_t lds = plan.lds;
+  if (plan.direct) {
+    if (fr.wide == nullptr) return hipErrorInvalidValue;
+    const int grid = grid_for(a.nrow, num_cus, 8);
+    if (a.pred_leaf) hipLaunchKernelGGL(predict_rows_direct_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, fr, a);
+    else hipLaunchKernelGGL(predict_rows_direct_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, fr, a);
+    return hipGetLastError();
+  }
+  const bool pf = plan.pf, listing = plan.listing;
+  if (plan.defer) {
+    const uint64_t want = a.nrow / 32 + 1024;                                   // room for ~3 % of the rows
+    a.defer_cap = listing ? (uint32_t)(want < tune.defer_words - 1 ? want : tune.defer_words - 1) : 0u;
+    a.defer_count = tune.defer_buf;
+    a.defer_list = tune.defer_buf + 1;
+    hipError_t e = hipMemsetAsync(a.defer_count, 0, sizeof(uint32_t), stream);
+    if (e == hipSuccess && listing) e = hipMemsetAsync(a.defer_list, 0xFF, (size_t)a.defer_cap * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+  }
+  const uint32_t split = plan.split;
+  if (split) a.shape = plan.split_shape;
 #define OHX_ROWS_T(FMT, CH, TOPS)                                                                                  \
   {                                                                                                                \
     if (split) return launch_rows_split(predict_rows_tile_kernel<FMT, CH, false, TOPS>, lds, fr, a, num_cus, stream, tune, split); \
@@ -2078,10 +2169,7 @@ hipError_t launch_predict(KernelKind kind, const DeviceForest& fr, const Predict
 #define OHX_ROWS(FMT, CH)                    \
   if (fr.tree_tops) OHX_ROWS_T(FMT, CH, true); \
   OHX_ROWS_T(FMT, CH, false)
-  // the ring kernel takes the OH shape with the next rows in flight (a big batch); everything else of a booster
-  // that asked for it - small batches with their trees split over waves, other column counts, the second launch of
-  // the deferred rows - goes the super2 way
-  if (kind == KernelKind::Ring && pf && !split && a.tree_end > a.tree_begin) {
+  if (plan.ring) {
     hipError_t e_ = launch_rows_ring(fr, a, num_cus, stream, tune);
     if (e_ == hipSuccess && listing)
       e_ = launch_deferred(predict_rows_tile_kernel<2, 2, false, true>, lds, fr, a, num_cus, stream);
@@ -2116,6 +2204,33 @@ std::string predict_kernel_symbol(KernelKind kind, const DeviceForest& fr, uint3
          (pf ? ",true," : ",false,") + (is_super && fr.tree_tops ? "true>" : "false>");
 }
 
+// Every __global__ a predict on this batch launches, in order, joined by " + " (OHXBoosterKernelSymbolRows).
+std::string predict_kernel_symbols_rows(KernelKind kind, const DeviceForest& fr, const PredictArgs& a, int num_cus,
+                                        const LaunchTuning& tune) {
+  const RowsPlan p = plan_rows(kind, fr, a, num_cus, tune);
+  if (a.nrow == 0 || !p.ok) return "";
+  if (p.direct) return a.pred_leaf ? "predict_rows_direct_kernel<true>" : "predict_rows_direct_kernel<false>";
+  int chains = 2;
+  if (kind == KernelKind::Packed1 || kind == KernelKind::Super1) chains = 1;
+  if (kind == KernelKind::Super3) chains = 3;
+  if (kind == KernelKind::Packed4 || kind == KernelKind::Super4) chains = 4;
+  const bool tops = p.is_super && fr.tree_tops;
+  auto tile = [&](bool prefetch) {
+    return std::string("predict_rows_tile_kernel<") + (p.is_super ? "2," : "1,") + std::to_string(chains) +
+           (prefetch ? ",true," : ",false,") + (tops ? "true>" : "false>");
+  };
+  if (p.split) return tile(false) + " + combine_leaves_kernel";
+  std::string out;
+  if (p.ring) {
+    out = "predict_rows_ring_kernel + predict_rows_tile_kernel<2,2,true,true> (only after a ring time-out) + ring_settle_kernel";
+    if (p.listing) out += " + predict_rows_tile_kernel<2,2,false,true> (rows with missing values)";
+    return out;
+  }
+  out = tile(p.pf);
+  if (p.listing) out += " + " + tile(false) + " (rows with missing values)";
+  return out;
+}
+
 // Same train of launches as the row kernels: a launch per `launches_per_residency` residencies
 // keeps the waves of an XCD on the same few trees.
 template <class K>
@@ -2136,9 +2251,10 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
   if (a.shape.ntiles(nrow) >= 0xFFFFFFFFull) a.shape = TileShape();
   const uint64_t ntiles = a.shape.ntiles(nrow);
   int grid = tile_grid(kernel, lds, ntiles, num_cus);
-  if (ring) {        // one block per CU
+  if (ring) {        // one block per CU, less the CUs left free for a collective's kernels (LaunchTuning::reserve_cus)
     const uint64_t blocks = (ntiles + waves_per_block - 1) / waves_per_block;
-    grid = (int)(blocks < (uint64_t)num_cus ? blocks : (uint64_t)num_cus);
+    const uint64_t cus = tune.reserve_cus > 0 && tune.reserve_cus < num_cus ? (uint64_t)(num_cus - tune.reserve_cus) : (uint64_t)num_cus;
+    grid = (int)(blocks < cus ? blocks : cus);
   }
   // rows with missing values are left to a second launch (PredictArgs::defer_list)
   constexpr uint64_t kDeferMinRows = 1u << 18;
@@ -2166,6 +2282,23 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
   }
   e = train.meet();
   if (e != hipSuccess) return e;
+  if (ring && a.flags != nullptr) {
+    // as launch_rows_ring: the tile kernel over all of the slab, predicated on kFlagRingTimeout, then the settle launch
+    auto again = predict_fields_kernel<2, 2, true>;
+    const size_t lds2 = tile_lds_bytes(fr.num_feature, true);
+    e = ensure_lds(again, lds2);
+    if (e != hipSuccess) return e;
+    FieldsArgs b = a;
+    b.only_if_flag = kFlagRingTimeout;
+    b.defer_list = nullptr;
+    b.defer_count = nullptr;
+    b.defer_cap = 0;
+    b.tile_begin = 0;
+    b.tile_end = ntiles;
+    hipLaunchKernelGGL(again, dim3(tile_grid(again, lds2, ntiles, num_cus)), dim3(kBlock), lds2, stream, fr, b, fr.super_heads,
+                       b.out, b.margin_out);
+    hipLaunchKernelGGL(ring_settle_kernel, dim3(1), dim3(kWave), 0, stream, a.flags);
+  }
   if (a.defer_list != nullptr && a.defer_cap != 0u) {
     // the second launch: the listed rows, 64 per wave, every lane gathering its own row from the fields
     a.perm = a.defer_list;
@@ -2338,6 +2471,7 @@ hipError_t launch_post_process(const PostArgs& a, hipStream_t stream) {
 // Many arrays moved by ONE launch: array a of the list is copied by the blocks (*, a).  Either side may be the
 // caller's registered host memory, which the GPU reads and writes over PCIe directly (capi.cpp HostRegistry): forty
 // copies of a rank-sized block's arrays cost forty times a copy's fixed price, one launch costs one.
+namespace {
 __global__ __launch_bounds__(kBlock) void copy_arrays_kernel(CopyList l) {
   const uint32_t a = blockIdx.y;
   const float* __restrict__ src = l.src[a];
@@ -2355,6 +2489,7 @@ __global__ __launch_bounds__(kBlock) void copy_arrays_kernel(CopyList l) {
     for (uint64_t i = t; i < n; i += stride) dst[i] = src[i];
   }
 }
+}  // namespace
 
 hipError_t launch_copy_arrays(const CopyList& l, hipStream_t stream) {
   if (l.count == 0) return hipSuccess;

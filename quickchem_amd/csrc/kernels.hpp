@@ -12,7 +12,11 @@ namespace ohx {
 // Flag bits the kernels raise in a device word
 enum : uint32_t {
   kFlagInfInput = 1u,  // an input value was +-inf while `missing` is finite
-  kFlagRingTimeout = 2u,  // ring kernels: a wave gave up waiting for another (the results are invalid)
+  // ring kernels: a wave gave up waiting for another and its block's results are not written.  Not an error any more:
+  // the launchers put a launch of the tile kernel behind every ring train that only runs when it finds this bit set
+  // (PredictArgs::only_if_flag) and walks the train's rows again, then ring_settle_kernel clears the bit and counts the
+  // event in the word after the flags (flags[1]; OHXBoosterGetInfo "ring_reruns")
+  kFlagRingTimeout = 2u,
 };
 
 // trees whose first-step super-nodes the tile kernels keep in LDS (kernels.hip)
@@ -113,7 +117,8 @@ struct PredictArgs {
   uint32_t tree_begin = 0, tree_end = 0;
   float* out = nullptr;         // [nrow] margins, or [nrow][ntree] leaf ids when pred_leaf
   bool pred_leaf = false;
-  uint32_t* flags = nullptr;    // device word, OR-ed with kFlag*
+  uint32_t* flags = nullptr;    // two device words: [0] OR-ed with kFlag*, [1] ring re-runs counted by ring_settle_kernel
+  uint32_t only_if_flag = 0;    // tile kernels: not 0 = every block leaves at once unless flags[0] holds one of these bits
   uint64_t tile_begin = 0;      // first 64-row tile of this launch (tile kernels)
   uint64_t tile_end = 0;        // one past the last tile of this launch
   int xcd_remap = 1;            // give each XCD a contiguous range of tiles
@@ -218,7 +223,8 @@ struct FieldsArgs {
   float scale = 1.0f;          // then * OHscale (OH_GridCompMod.F90:1569)
   float* out = nullptr;        // (im,jm,km) array; only levels k1..k2 are written
   float* margin_out = nullptr; // optional [N] raw margins in slab row order
-  uint32_t* flags = nullptr;
+  uint32_t* flags = nullptr;   // as PredictArgs::flags
+  uint32_t only_if_flag = 0;   // as PredictArgs::only_if_flag
   uint64_t tile_begin = 0, tile_end = 0;   // 64-row tiles of this launch
   int xcd_remap = 1;           // give each XCD a contiguous range of tiles
   TileShape shape;             // lanes -> gridcells of the slab
@@ -300,6 +306,9 @@ enum class KernelKind { Wide, Packed1, Packed2, Packed4, Super1, Super2, Super3,
 const char* kernel_kind_name(KernelKind k);
 // the __global__ launch_predict would launch for rows of `ncol` columns (for profiles and bench.py)
 std::string predict_kernel_symbol(KernelKind kind, const DeviceForest& forest, uint32_t ncol, const LaunchTuning& tune);
+// ... and every kernel a predict on the batch `a` launches, in order, joined by " + "
+std::string predict_kernel_symbols_rows(KernelKind kind, const DeviceForest& fr, const PredictArgs& a, int num_cus,
+                                        const LaunchTuning& tune);
 
 hipError_t launch_predict(KernelKind kind, const DeviceForest& forest, const PredictArgs& a, int num_cus,
                           hipStream_t stream, const LaunchTuning& tune = LaunchTuning());

@@ -848,6 +848,88 @@ def test_ring_fused_fields_vs_oracle(torch_cuda, deep_model, dynamic):
         assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2
 
 
+RING_SPIN1 = os.path.join(helpers.ROOT, "tools", "bin", "variants", "ringspin1", "libohxgb.so")
+
+
+def test_a_ring_time_out_is_predicted_again_not_raised(torch_cuda, deep_model, capfd):
+    """a ring block that gives up waiting used to end in rc -1 ("error flags 2") and the caller's
+    _ASSERT(rc==0) (OH_GridCompMod.F90:356-358).  A scratch build whose waves give up after ONE look (tools/build_variant.sh
+    ringspin1 -DOHX_EXP_RING_SPIN=1, made by __graft_entry__.build()) times out in nearly every block: the launch behind
+    the train - the tile kernel, which only runs when the time-out bit is set - predicts the rows again, the bit is
+    cleared, the event counted.  Margins bit for bit against the oracle: the host form, the device form without
+    OHXBoosterCheck, with and without missing values, and the fused fields call."""
+    if not os.path.exists(RING_SPIN1):
+        pytest.skip("tools/bin/variants/ringspin1 not built")
+    import ctypes as C
+    import torch
+    lib = capi.load_library(RING_SPIN1)
+    grid = (96, 72, 72)
+    nrow = 96 * 72 * 40
+    for rate in (0.0, 2e-3):
+        rows = synth.rows_cpu(grid, 0, nrow)
+        if rate:
+            rows = with_missing(rows, rate, seed=5)
+        want = helpers.oracle_predict(deep_model.image, rows, synth.XX_MISS)
+        b = capi.Booster(model_buffer=deep_model.image, lib=lib)
+        b.set_param("ohx_kernel", "ring")
+        b.set_param("ohx_tree_split", "off")
+        assert b.ring_reruns() == 0
+        d = capi.DMatrix(rows, missing=synth.XX_MISS, lib=lib)
+        d.set_grid(96, 72, 0)
+        assert "only after a ring time-out" in b.kernel_symbols_for(d)
+        got = b.predict(d)                                            # rc 0: no error is raised
+        assert np.array_equal(helpers.bits(got), helpers.bits(want)), rate
+        first = b.ring_reruns()
+        assert first > 0
+        # the device form: stream-ordered, nobody calls OHXBoosterCheck
+        dev_rows = torch.from_numpy(rows).cuda()
+        out = torch.full((nrow,), float("nan"), dtype=torch.float32, device="cuda")
+        dd = capi.DMatrix(device_ptr=dev_rows.data_ptr(), nrow=nrow, ncol=27, missing=synth.XX_MISS, lib=lib)
+        dd.set_grid(96, 72, 0)
+        b.predict_device(dd, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(helpers.bits(out.cpu().numpy()), helpers.bits(want)), rate
+        assert b.ring_reruns() > first
+        b.check()                                                     # and nothing is left to raise
+        dd.free()
+        d.free()
+        b.free()
+    assert "gave up waiting" in capfd.readouterr().err               # said once on stderr
+    # the fused fields call on a slab big enough for predict_fields_ring_kernel
+    fgrid = (144, 96, 80)
+    pl, tropp, fields = helpers.synth_state(fgrid)
+    oh_ref, margin_ref, k1, k2 = helpers.oracle_predict_oh(deep_model.image, pl, tropp, fields, True)
+    assert fgrid[0] * fgrid[1] * (k2 - k1 + 1) >= 256 * 16 * 64 * 2
+    p = oh_predict.OHPredictor()
+    p.xx_bst = capi.Booster(model_buffer=deep_model.image, lib=lib)
+    p.xx_bst.set_param("ohx_kernel", "ring")
+    p.first_time = False
+    oh = np.zeros(fgrid, dtype=np.float32)
+    margins = []
+    assert p.predict_OH_with_XGB("unused", *fgrid, True, 4000.0, pl, tropp, oh_predict.OHBoostInputData(fields), oh,
+                                 mode="fused", margin_out=margins) == 0
+    assert np.array_equal(helpers.bits(margins[0]), helpers.bits(margin_ref))
+    assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2
+    assert p.xx_bst.ring_reruns() > 0
+
+
+def test_the_shipped_ring_kernel_does_not_time_out(torch_cuda, deep_model):
+    """... and the library as shipped goes through the same batches without a single re-run."""
+    grid = (96, 72, 72)
+    rows = synth.rows_cpu(grid, 0, 96 * 72 * 40)
+    b = capi.Booster(model_buffer=deep_model.image)
+    b.set_param("ohx_kernel", "ring")
+    b.set_param("ohx_tree_split", "off")
+    d = capi.DMatrix(rows, missing=synth.XX_MISS)
+    d.set_grid(96, 72, 0)
+    want = helpers.oracle_predict(deep_model.image, rows, synth.XX_MISS)
+    for _ in range(5):
+        assert np.array_equal(helpers.bits(b.predict(d)), helpers.bits(want))
+    assert b.ring_reruns() == 0
+    d.free()
+    b.free()
+
+
 @pytest.mark.parametrize("kernel", ["super1", "super2", "super4", "ring", "auto"])
 def test_fused_fields_small_slab_with_its_trees_split_over_waves(torch_cuda, deep_model, kernel):
     """The fused call on a slab that leaves the chip mostly empty (a GEOS rank's block): its trees are cut into runs

@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void valu_kernel(int iters, uint32_t seed, uin
   float f0 = (float)a0, f1 = (float)a1 * 0.5f, f2 = (float)a2 * 0.25f, f3 = (float)a3 * 0.125f;
   const uint32_t b = seed | 1u;
   const float fb = (float)(seed & 0xFFu) + 0.5f;
-  unsigned long long t0, t1;
-  asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  unsigned long long t0, t1, r0, r1;
+  asm volatile("s_waitcnt lgkmcnt(0)\n s_memrealtime %1\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
   for (int it = 0; it < iters; ++it) {
     if (KIND == K_ADD) {
 #pragma unroll
@@ -178,10 +178,14 @@ __global__ __launch_bounds__(256) void valu_kernel(int iters, uint32_t seed, uin
       a4 ^= t2_ ^ t6_ ^ t10_ ^ t14_;
     }
   }
-  asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
   const uint32_t acc = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ __float_as_uint(f0 + f1 + f2 + f3);
   if (acc == 0x12345678u) sink[0] = acc + lds_pad[0];   // keep everything alive
-  if ((threadIdx.x & 63u) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+  if ((threadIdx.x & 63u) == 0) {
+    const size_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    cycles[2 * w] = t1 - t0;          // s_memtime: shader-clock ticks
+    cycles[2 * w + 1] = r1 - r0;      // s_memrealtime: the constant 100 MHz reference clock
+  }
 }
 
 typedef void (*kernel_t)(int, uint32_t, uint32_t*, unsigned long long*);
@@ -203,8 +207,10 @@ int main(int argc, char** argv) {
          iters);
   printf("# cyc/instr/SIMD = (s_memtime ticks of the median wave) x waves on the SIMD / instructions the SIMD issued;\n");
   printf("# wall = the same from the launch's event time at the nominal clock.  One block = one wave per SIMD.\n");
-  printf("%-22s %10s %12s %16s %16s %12s\n", "instruction", "waves/SIMD", "wall ms", "cyc/instr (wall)", "cyc/instr (tick)",
-         "tick/wall");
+  printf("# shader MHz = s_memtime ticks per microsecond of s_memrealtime (100 MHz) over the median wave's span;\n");
+  printf("# span = that span / the launch's event time (1.0 = every wave ran from the launch's start to its end)\n");
+  printf("%-22s %10s %12s %16s %16s %12s %10s\n", "instruction", "waves/SIMD", "wall ms", "cyc/instr (wall)", "cyc/instr (tick)",
+         "shader MHz", "span");
   uint32_t* sink;
   CHECK(hipMalloc(&sink, 4));
   const int wlist[] = {1, 2, 4, 8};
@@ -213,12 +219,14 @@ int main(int argc, char** argv) {
     for (int wi = 0; wi < 4; ++wi) {
       const int w = wlist[wi];
       if (only_w >= 0 && w != only_w) continue;
-      // w blocks per CU and no more: each takes 1/w of the CU's LDS (less a little for alignment)
-      const int lds = (lds_max / w) - 1024;
+      // w blocks per CU and no more: each takes 1/w of the CU's 160 KB of LDS (less a little for alignment) - the
+      // attribute reports the 64 KB a block gets by default, which would let two "one per CU" blocks share a CU
+      (void)lds_max;
+      const int lds = (160 * 1024 / w) - 2048;
       CHECK(hipFuncSetAttribute((const void*)kKernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       const int blocks = cus * w;
       unsigned long long* cyc;
-      CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * blocks * 4));
+      CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * blocks * 4 * 2));
       hipEvent_t e0, e1;
       CHECK(hipEventCreate(&e0));
       CHECK(hipEventCreate(&e1));
@@ -229,15 +237,18 @@ int main(int argc, char** argv) {
       CHECK(hipEventSynchronize(e1));
       float ms = 0;
       CHECK(hipEventElapsedTime(&ms, e0, e1));
-      std::vector<unsigned long long> h(blocks * 4);
-      CHECK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<unsigned long long> both(blocks * 4 * 2), h(blocks * 4), real(blocks * 4);
+      CHECK(hipMemcpy(both.data(), cyc, both.size() * 8, hipMemcpyDeviceToHost));
+      for (size_t q = 0; q < h.size(); ++q) h[q] = both[2 * q], real[q] = both[2 * q + 1];
       std::sort(h.begin(), h.end());
+      std::sort(real.begin(), real.end());
       const double ticks = (double)h[h.size() / 2];
+      const double shader_mhz = ticks / ((double)real[real.size() / 2] / 100.0);     // ticks per microsecond of the wave's span
+      const double span_frac = ((double)real[real.size() / 2] / 100.0) / (ms * 1e3);  // the median wave's span over the launch's
       const double instr_per_simd = (double)w * iters * kPerTrip[k];
       const double cyc_wall = ms * 1e-3 * clock_khz * 1e3 / instr_per_simd;
       const double cyc_tick = ticks / instr_per_simd;   // the median wave's span over what its SIMD issued meanwhile
-      printf("%-22s %10d %12.3f %16.2f %16.2f %12.3f\n", kKindName[k], w, ms, cyc_wall, cyc_tick,
-             ticks / (ms * 1e-3 * clock_khz * 1e3));
+      printf("%-22s %10d %12.3f %16.2f %16.2f %12.0f %10.2f\n", kKindName[k], w, ms, cyc_wall, cyc_tick, shader_mhz, span_frac);
       CHECK(hipFree(cyc));
     }
   }
