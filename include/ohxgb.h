@@ -109,7 +109,11 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *                     they are seen and moved by DMA - a rank-sized block's forty arrays by ONE copy launch - from
  *                     then on (a 48 x 24 x 72 block's Run1 tick: 0.98 -> 0.52 ms; six ranks sharing the GPU: 3.3 ->
  *                     0.7 ms).  A CONTRACT: every array passed while this is on must stay allocated until
- *                     OHXReleaseScratch() or the end of the process (MAPL's state arrays do).  Default 0
+ *                     OHXUnregisterHost(array), OHXReleaseScratch() or the end of the process (MAPL's state arrays
+ *                     do); an array that is freed while registered is reached through a registration the library
+ *                     cannot check - ROCm's follows the process's page tables, so the next copy faults rather than
+ *                     reads stale pages, but it fails.  Nothing is unregistered under a copy in flight (the device
+ *                     is synchronised first).  Default 0 (the OH shell turns it on: register_host_arrays, default T)
  *   "ohx_tree_tops"   auto | on | off : super-nodes: fetch a tree's first records with one coalesced load per
  *                     wavefront (auto = forests of 7 or more steps per tree, where it is faster)
  *   "ohx_cluster"     auto | on | off : group rows of no known order by the decisions they take at the top of
@@ -333,10 +337,14 @@ int OHXShardRows(bst_ulong nrows_total, int nranks, int rank, bst_ulong* row0, b
 int OHXAllGatherOH(OHXCommHandle comm, const float* d_shard, bst_ulong nrows_local, bst_ulong nrows_total,
                    float* d_full, void* stream);
 
+/* An array that was handed over while "ohx_register_host" was on is about to be freed or reallocated: its registration
+ * goes (after the device has been synchronised).  An array the library never registered is not an error. */
+int OHXUnregisterHost(const void* array);
+
 /* Returns the device buffers the library keeps between calls to the driver: freed DMatrix storage parked
  * for the next XGDMatrixCreateFromMat (the reference creates and frees its matrix on every OH tick,
  * OH_GridCompMod.F90:347,377; at most two buffers are kept; OHX_DMATRIX_POOL=0 in the environment keeps
- * none).  Live handles are not touched. */
+ * none), and drops every host registration ("ohx_register_host").  Live handles are not touched. */
 int OHXReleaseScratch(void);
 
 #ifdef __cplusplus

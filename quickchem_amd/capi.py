@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXDMatrixInferGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device", "OHXOHPostProcess", "OHXOHPostProcessDevice",
     "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXBoosterKernelSymbol", "OHXBoosterKernelSymbolRows",
-    "OHXBoosterRingReruns", "OHXReleaseScratch",
+    "OHXBoosterRingReruns", "OHXUnregisterHost", "OHXReleaseScratch",
     "OHXCommGetUniqueId", "OHXCommInitRank", "OHXCommFree", "OHXCommInfo", "OHXShardRows", "OHXAllGatherOH",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
@@ -124,6 +124,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.OHXBoosterKernelSymbol.argtypes = [vp, u64, C.POINTER(C.c_char_p)]
     lib.OHXBoosterKernelSymbolRows.argtypes = [vp, vp, C.POINTER(C.c_char_p)]
     lib.OHXBoosterRingReruns.argtypes = [vp, vp, C.POINTER(u64)]
+    lib.OHXUnregisterHost.argtypes = [vp]
     lib.OHXReleaseScratch.argtypes = []
     lib.OHXCommGetUniqueId.argtypes = [vp]
     lib.OHXCommInitRank.argtypes = [vp, i32, i32, C.POINTER(vp)]

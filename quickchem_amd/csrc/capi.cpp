@@ -230,9 +230,14 @@ RowPool g_row_pool;
 // about as much as ten ticks and is done once per array: (pointer, bytes) is remembered, and MAPL's import, export
 // and internal pointers are the same from tick to tick (OH_GridCompMod.F90:1136,1195: MAPL_GetPointer on states that
 // live as long as the run).  It is OPT-IN because it is a contract: an array that was passed while this is on must
-// stay allocated until OHXReleaseScratch() or the end of the process - memory that is freed and handed out again at
-// the same address would still be reached through the old registration.  What the driver refuses to register
-// (it happens to ranges that share a page with another registration) is copied the pageable way as before.
+// stay allocated until OHXUnregisterHost(array), OHXReleaseScratch() or the end of the process.  What happens to an
+// array that is freed while registered is the driver's business, not this table's: ROCm pins registered ranges
+// through KFD userptr objects that follow the process's page tables (a range that is unmapped is invalidated, a later
+// GPU access to it faults; one that is mapped again is pinned again), so the failure is loud rather than stale - but
+// it is a failure, hence the contract, and hence OHXUnregisterHost for a caller whose arrays do come and go.
+// Nothing is unregistered while a copy may be in flight: the device is synchronised first.  What the driver
+// refuses to register (it happens to ranges that share a page with another registration) is copied the pageable way
+// as before.
 struct HostRegistry {
   std::mutex mu;
   std::atomic<bool> on{false};
@@ -246,6 +251,7 @@ struct HostRegistry {
     auto it = pinned.find(p);
     if (it != pinned.end()) {
       if (it->second >= n) return true;
+      (void)hipDeviceSynchronize();                       // no copy of the old range may still be in flight
       (void)hipHostUnregister(const_cast<void*>(p));      // the same array, grown: again from the start
       bytes -= it->second;
       pinned.erase(it);
@@ -266,10 +272,23 @@ struct HostRegistry {
     if (getenv("OHX_REGISTRY_LOG") && (!pinned.empty() || !refused.empty()))
       fprintf(stderr, "[ohxgb] host registry: %zu arrays (%zu bytes) registered, %zu refused\n", pinned.size(), bytes,
               refused.size());
+    if (!pinned.empty()) (void)hipDeviceSynchronize();     // DMA targets are not unpinned under a running copy
     for (auto& kv : pinned) (void)hipHostUnregister(const_cast<void*>(kv.first));
     pinned.clear();
     refused.clear();
     bytes = 0;
+  }
+  // one array leaves (OHXUnregisterHost): true if it was registered
+  bool forget(const void* p) {
+    std::lock_guard<std::mutex> g(mu);
+    refused.erase(p);
+    auto it = pinned.find(p);
+    if (it == pinned.end()) return false;
+    (void)hipDeviceSynchronize();
+    (void)hipHostUnregister(const_cast<void*>(p));
+    bytes -= it->second;
+    pinned.erase(it);
+    return true;
   }
 };
 HostRegistry g_host_registry;
@@ -1870,6 +1889,12 @@ int OHXBoosterRingReruns(BoosterHandle handle, void* stream, bst_ulong* out) {
     HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     *out = n;
   }
+  API_END();
+}
+
+int OHXUnregisterHost(const void* array) {
+  API_BEGIN();
+  if (array != nullptr) (void)g_host_registry.forget(array);
   API_END();
 }
 

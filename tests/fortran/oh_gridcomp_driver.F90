@@ -3,6 +3,8 @@
 !  `nticks` heartbeats of Run phase 1, Run phase 2 and clock advance, through the ESMF / MAPL calls a cap makes, served by
 !  the mock in quickchem_amd/fortran/mapl_lite/ (no MAPL, no ESMF here).  The parent, QuickChem_GridCompMod, is the
 !  reference's own unmodified file, compiled in place by oracle/Makefile (target `ref`); the child is the product's -
+!  (built with -DOHX_STANDALONE_CAP the parent is the product's own quickchem_amd/fortran/oh_standalone_cap.F90: the drivers
+!  quickchem_amd/lib/oh_gridcomp_driver_hip and oracle/lib/oh_gridcomp_driver_oracle, which need no reference tree)
 !  or, built with -DOHX_REFERENCE_CHILD, the reference's own OH_GridComp/OH_GridCompMod.F90, also compiled in place (the
 !  drivers oracle/_ref/refchild/oh_refchild_driver_*: the reference's lines as the checker of the product's).  Being the mock's cap it also plays "the rest of GEOS": storage for
 !  the imports, HISTORY's wish list of exports, the model moving between heartbeats (esmfl_ / mapll_ calls).
@@ -31,7 +33,11 @@ program oh_gridcomp_driver
    use, intrinsic :: iso_c_binding
    use ESMF
    use MAPL
+#ifdef OHX_STANDALONE_CAP
+   use OH_StandaloneCap, only: QuickChem_SetServices => SetServices      ! the product's own minimal parent
+#else
    use QuickChem_GridCompMod, only: QuickChem_SetServices => SetServices, IS_QC_INSTANCE_RUNNING
+#endif
 #ifndef OHX_REFERENCE_CHILD
    use OH_GridCompMod, only: oh_last_run
 #endif
@@ -106,8 +112,10 @@ program oh_gridcomp_driver
    call MAPL_GetObjectFromGC(root, meta, rc)
    call MAPL_Get(meta, gcs=gcs, gim=gim, gex=gex, rc=rc)
    call ESMF_GridCompGet(gcs(1), name=child_name)
+#ifndef OHX_STANDALONE_CAP
    call IS_QC_INSTANCE_RUNNING('OH', trim(child_name), running, rc)
    if (rc /= ESMF_SUCCESS .or. .not. running) call die('IS_QC_INSTANCE_RUNNING does not know the first OH instance')
+#endif
 
    !  AGCM.rc `SPEC_DUMP: <file>`: what every instance's SetServices registered, one line per field -
    !  instance|state|short name|dims|vlocation|restart|refresh|averaging|ungridded|add2export|units|long name

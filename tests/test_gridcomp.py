@@ -1,9 +1,11 @@
 """SURVEY.md §8(f)-4 / BASELINE.json config #1 as worded: "a synthetic MAPL state through OH_GridComp Run".
 
-The OH GridComp shell (quickchem_amd/fortran/oh_gridcomp.F90, on the mapl_lite mock) runs as the child of the
-REFERENCE'S OWN parent: QuickChem_GridCompMod.F90 and Shared/QuickChem_Generic.F90, unmodified, compiled in place from
-/root/reference into oracle/_ref/ by oracle/Makefile (target `ref`; skipped where neither the reference nor a prebuilt
-oracle/_ref is there) - driven over model days by a mock GEOS cap (tests/fortran/oh_gridcomp_driver.F90).  Linked against the oracle it is the CPU
+The OH GridComp shell (quickchem_amd/fortran/oh_gridcomp.F90, on the mapl_lite mock) runs as the child of two parents
+in turn (fixture `drivers`): the product's own minimal one (quickchem_amd/fortran/oh_standalone_cap.F90; always built,
+its absence fails) and the REFERENCE'S OWN parent, QuickChem_GridCompMod.F90 and Shared/QuickChem_Generic.F90, unmodified,
+compiled in place from /root/reference into oracle/_ref/ by oracle/Makefile (target `ref`; that half is skipped where
+neither the reference nor a prebuilt oracle/_ref is there) - driven over model days by a mock GEOS cap
+(tests/fortran/oh_gridcomp_driver.F90).  Linked against the oracle it is the CPU
 plumbing case; linked against libohxgb.so (-m gpu) the same shell runs its arithmetic on the MI355X.  What the
 shell decides - alarm gate, need_to_call_BOOST, which import feeds which input (OH_data_source, spin-up), the month
 in the model file name, what persists between ticks - is restated here tick by tick in Python, and the numbers come
@@ -21,12 +23,28 @@ import pytest
 from quickchem_amd import capi, synth
 from tests import helpers
 
+# the mock GEOS cap (tests/fortran/oh_gridcomp_driver.F90) over the OH shell, under two parents:
+#   "cap"     the product's own minimal parent, quickchem_amd/fortran/oh_standalone_cap.F90 - built by
+#             quickchem_amd/fortran/Makefile and oracle/Makefile wherever the product builds; its absence FAILS the tests
+#   "parent"  the reference's own QuickChem_GridCompMod.F90, compiled in place by oracle/Makefile `ref` - an additional
+#             cross-check, skipped where neither /root/reference nor a prebuilt oracle/_ref is there
+CAP_ORACLE = os.path.join(helpers.ROOT, "oracle", "lib", "oh_gridcomp_driver_oracle")
+CAP_HIP = os.path.join(helpers.ROOT, "quickchem_amd", "lib", "oh_gridcomp_driver_hip")
 DRIVER_ORACLE = os.path.join(helpers.ROOT, "oracle", "_ref", "oh_gridcomp_driver_oracle")
 DRIVER_HIP = os.path.join(helpers.ROOT, "oracle", "_ref", "oh_gridcomp_driver_hip")
 
-pytestmark = pytest.mark.skipif(not os.path.exists(DRIVER_ORACLE),
-                                reason="oracle/_ref not built: the parent grid component is the reference's own file "
-                                       "(/root/reference/QuickChem_GridCompMod.F90), compiled in place by oracle/Makefile")
+
+@pytest.fixture(params=["cap", "parent"])
+def drivers(request):
+    if request.param == "cap":
+        assert os.path.exists(CAP_ORACLE) and os.path.exists(CAP_HIP), \
+            "the product's GridComp drivers are missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+        return {"oracle": CAP_ORACLE, "hip": CAP_HIP, "which": "cap"}
+    if not os.path.exists(DRIVER_ORACLE):
+        pytest.skip("oracle/_ref not built: the reference's own parent (/root/reference/QuickChem_GridCompMod.F90) is "
+                    "compiled in place by oracle/Makefile")
+    return {"oracle": DRIVER_ORACLE, "hip": DRIVER_HIP, "which": "parent"}
+
 
 F32 = np.float32
 EPSILON = float(F32(18.015) / F32(28.965))        # MAPL_H2OMW / MAPL_AIRMW in real32, as mapl_lite computes it
@@ -305,19 +323,19 @@ def check_two_days(grid, got, want, log, on_gpu):
     assert not np.array_equal(got[0]["OH"]["OH_boost"], got[48]["OH"]["OH_boost"])
 
 
-def test_config1_two_model_days_through_the_gridcomp_on_the_cpu(tmp_path, small_model):
-    grid, got, want, log = two_day_case(tmp_path, small_model, DRIVER_ORACLE, on_gpu=False)
+def test_config1_two_model_days_through_the_gridcomp_on_the_cpu(tmp_path, small_model, drivers):
+    grid, got, want, log = two_day_case(tmp_path, small_model, drivers["oracle"], on_gpu=False)
     check_two_days(grid, got, want, log, on_gpu=False)
 
 
 @pytest.mark.gpu
-def test_two_model_days_through_the_gridcomp_on_the_gpu(tmp_path, small_model):
-    grid, got, want, log = two_day_case(tmp_path, small_model, DRIVER_HIP, on_gpu=True)
+def test_two_model_days_through_the_gridcomp_on_the_gpu(tmp_path, small_model, drivers):
+    grid, got, want, log = two_day_case(tmp_path, small_model, drivers["hip"], on_gpu=True)
     check_two_days(grid, got, want, log, on_gpu=True)
 
 
 @pytest.mark.parametrize("source", ["PRECOMPUTED", "ONLINE_INST"])
-def test_data_sources_and_the_reference_model_policy(tmp_path, small_model, source):
+def test_data_sources_and_the_reference_model_policy(tmp_path, small_model, source, drivers):
     """The other two OH_data_source settings, Boost at every alarm (compute_once_per_day: F -> dynamic k range),
     default alarm phase (no OH_REFERENCE_TIME: it rings during the LAST heartbeat of each OH_DT interval), and the
     reference's model policy: the file of the first call for good, whatever month the name says."""
@@ -334,7 +352,7 @@ def test_data_sources_and_the_reference_model_policy(tmp_path, small_model, sour
                  exports=[e for e, _ in ex], **cfg)
     state, out = tmp_path / "state.bin", tmp_path / "out.bin"
     write_state_file(state, grid, imports, lats, lons)
-    r = run_driver(DRIVER_ORACLE, rundir, state, out, 8)
+    r = run_driver(drivers["oracle"], rundir, state, out, 8)
     assert r.returncode == 0, r.stdout[-3000:]
     got = parse_output(out, grid, [("OH", False)], ex)
     want = emulate(grid, imports, lats, lons, 8, models={1: small_model.image, 2: other.image}, ref_hms=0,
@@ -350,7 +368,7 @@ def test_data_sources_and_the_reference_model_policy(tmp_path, small_model, sour
     assert got[7]["OH"]["model"].endswith("oh_M02.model")     # the expanded name rolled over; the booster did not
 
 
-def test_setservices_refuses_what_the_reference_refuses(tmp_path, small_model):
+def test_setservices_refuses_what_the_reference_refuses(tmp_path, small_model, drivers):
     grid = (4, 3, 12)
     imports, lats, lons = mock_imports(grid, "ONLINE_INST")
     state, out = tmp_path / "state.bin", tmp_path / "out.bin"
@@ -359,15 +377,15 @@ def test_setservices_refuses_what_the_reference_refuses(tmp_path, small_model):
     base = dict(model_pattern=str(tmp_path / "m.model"), exports=[])
     # an OH_data_source that is none of the three: VERIFY_(99) (:549-559)
     write_rundir(tmp_path / "a", source="ONLINE", **base)
-    r = run_driver(DRIVER_ORACLE, tmp_path / "a", state, out, 1)
+    r = run_driver(drivers["oracle"], tmp_path / "a", state, out, 1)
     assert r.returncode != 0 and "Invalid OH_data_source: ONLINE" in r.stdout
     # the wavelength OH wants is not among GOCART2G's (:586-590)
     write_rundir(tmp_path / "b", source="ONLINE_INST", wavelength=532, **base)
-    r = run_driver(DRIVER_ORACLE, tmp_path / "b", state, out, 1)
+    r = run_driver(drivers["oracle"], tmp_path / "b", state, out, 1)
     assert r.returncode != 0 and "Did not find OH wavelength_for_scacoef" in r.stdout
     # a model file that is not there: the first Boost fails, Run returns an error
     write_rundir(tmp_path / "c", source="ONLINE_INST", model_pattern=str(tmp_path / "nope_%m2.model"), exports=[])
-    r = run_driver(DRIVER_ORACLE, tmp_path / "c", state, out, 2)
+    r = run_driver(drivers["oracle"], tmp_path / "c", state, out, 2)
     assert r.returncode != 0 and "Run phase 1 failed" in r.stdout
     # a tropopause at or below 40 hPa with the static k range (:287-288)
     low = dict(imports)
@@ -375,11 +393,11 @@ def test_setservices_refuses_what_the_reference_refuses(tmp_path, small_model):
     low["TROPP"][1, 1] = 3900.0
     write_state_file(tmp_path / "low.bin", grid, low, lats, lons)
     write_rundir(tmp_path / "d", source="ONLINE_INST", once_per_day=True, **base)
-    r = run_driver(DRIVER_ORACLE, tmp_path / "d", tmp_path / "low.bin", out, 1)
+    r = run_driver(drivers["oracle"], tmp_path / "d", tmp_path / "low.bin", out, 1)
     assert r.returncode != 0 and "Minimum tropopause pressure is not low enough" in r.stdout
 
 
-def test_passive_data_instance_and_a_start_after_midnight(tmp_path, small_model):
+def test_passive_data_instance_and_a_start_after_midnight(tmp_path, small_model, drivers):
     """QuickChem_GridComp.rc lists: an active computational instance and a passive data-driven one
     (its name contains 'data': Run_data copies its import climoh001 into INTERNAL OH, no phase 2).  The run starts at 06:00 with
     compute_once_per_day: Boost is not due until midnight, and INTERNAL OH is built from the zero-filled OH_ML
@@ -394,7 +412,7 @@ def test_passive_data_instance_and_a_start_after_midnight(tmp_path, small_model)
     state, out = tmp_path / "state.bin", tmp_path / "out.bin"
     clim = (np.random.default_rng(4).random(grid) * 1e-13).astype(F32)
     write_state_file(state, grid, dict(imports, climoh001=clim), lats, lons)
-    r = run_driver(DRIVER_ORACLE, rundir, state, out, 3)
+    r = run_driver(drivers["oracle"], rundir, state, out, 3)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "OH_instance_OH.data.rc does not exist" in r.stdout
     got = parse_output(out, grid, [("OH", False), ("OH.data", True)], [("OH_boost", False)])
@@ -408,7 +426,7 @@ def test_passive_data_instance_and_a_start_after_midnight(tmp_path, small_model)
     assert np.all(got[0]["OH"]["OH"][~below] > 0)                  # default_OH * NDWET * 1e-6 above the tropopause
 
 
-def test_mapl_lite_config_reader(tmp_path):
+def test_mapl_lite_config_reader(tmp_path, drivers):
     """The ESMF_Config subset through a tiny Fortran-free check: the driver refuses an rc without BEG_DATE, reads
     '#' comments, logical spellings and vectors (exercised by every case above); here the odd spellings."""
     grid = (3, 3, 8)
@@ -423,14 +441,14 @@ def test_mapl_lite_config_reader(tmp_path):
         .replace("spinup_24hr_imports: F", "spinup_24hr_imports: no"))
     agcm = (rundir / "AGCM.rc").read_text().replace("BEG_DATE: 20240131 000000", "BEG_DATE: 20240131 003000")
     (rundir / "AGCM.rc").write_text(agcm)
-    r = run_driver(DRIVER_ORACLE, rundir, state, out, 2)
+    r = run_driver(drivers["oracle"], rundir, state, out, 2)
     assert r.returncode == 0, r.stdout[-2000:]               # nhms = 003000 > 0 and once per day: no model file needed
     got = parse_output(out, grid, [("OH", False)], [])
     # ring times are on the hour (OH_REFERENCE_TIME = one heartbeat): silent at 00:30, ringing at 01:00
     assert got[0]["nhms"] == 3000 and not got[0]["OH"]["ran"]
     assert got[1]["nhms"] == 10000 and got[1]["OH"]["ran"] and not got[1]["OH"]["boosted"]
     (rundir / "AGCM.rc").write_text(agcm.replace("BEG_DATE", "BEGIN"))
-    r = run_driver(DRIVER_ORACLE, rundir, state, out, 1)
+    r = run_driver(drivers["oracle"], rundir, state, out, 1)
     assert r.returncode != 0 and "BEG_DATE" in r.stdout
 
 
@@ -491,7 +509,7 @@ def registered_specs(path):
 
 @pytest.mark.parametrize("source,spinup", [("PRECOMPUTED", False), ("ONLINE_INST", False), ("ONLINE_AVG24", False),
                                            ("ONLINE_AVG24", True)])
-def test_setservices_registers_the_reference_spec_table(tmp_path, small_model, source, spinup):
+def test_setservices_registers_the_reference_spec_table(tmp_path, small_model, source, spinup, drivers):
     """Every field the reference's OH SetServices registers - the rows of OH_StateSpecs.rc and the ADD_IMPORT_* lines of
     OH_GridCompMod.F90:611-634,693-783, as tests/golden/oh_specs.json holds them - is registered by the product's with
     the same short name, dims, vlocation, restart, refresh / averaging interval, ungridded dimension, units and long
@@ -507,7 +525,7 @@ def test_setservices_registers_the_reference_spec_table(tmp_path, small_model, s
     write_rundir(rundir, source=source, spinup=spinup, model_pattern="/nonexistent", exports=[], passive="OH.data")
     with open(rundir / "AGCM.rc", "a") as f:
         f.write(f"SPEC_DUMP: {tmp_path / 'specs.txt'}\n")
-    r = run_driver(DRIVER_ORACLE, rundir, state, out, 0)
+    r = run_driver(drivers["oracle"], rundir, state, out, 0)
     assert r.returncode == 0, r.stdout[-2000:]
     got = registered_specs(tmp_path / "specs.txt")
     assert set(got) == {"OH", "OH.data"}

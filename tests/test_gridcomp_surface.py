@@ -13,7 +13,7 @@ import re
 from tests import helpers
 
 FORTRAN = os.path.join(helpers.ROOT, "quickchem_amd", "fortran")
-SHELL = [os.path.join(FORTRAN, "oh_gridcomp.F90")]
+SHELL = [os.path.join(FORTRAN, "oh_gridcomp.F90"), os.path.join(FORTRAN, "oh_standalone_cap.F90")]
 
 
 def test_the_parent_is_not_in_this_repository():
