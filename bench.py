@@ -73,10 +73,18 @@ def parse_args():
     ap.add_argument("--gather-chunks", type=int, default=6,
                     help="N > 1: cut the shard into this many pieces so that a piece's all-gather overlaps the next "
                          "piece's prediction (1 = predict everything, then one all-gather)")
-    ap.add_argument("--gather", default="torch", choices=["torch", "native", "none"],
+    ap.add_argument("--gather-gbps", type=float, default=None,
+                    help="the planner's price of the all-gather, GB/s taken in per rank (default: OHX_GATHER_GBPS, else "
+                         "shard.GATHER_BYTES_PER_S - a guess until an N > 1 run has been measured)")
+    ap.add_argument("--piece-rounds", type=float, default=None,
+                    help="the planner's price of one more piece, in rounds of the chip (default: OHX_PIECE_ROUNDS, else "
+                         "shard.PIECE_ROUNDS)")
+    ap.add_argument("--gather", default="both", choices=["both", "torch", "native", "none"],
                     help="N > 1: the all-gather through torch.distributed (RCCL process group), through the C ABI's "
                          "own OHXAllGatherOH (what a Fortran/MPI host would call), or not at all (a control: predict "
-                         "only, so that a weak scaling curve can be split into prediction and exchange; not a result)")
+                         "only, so that a scaling curve can be split into prediction and exchange; not a result).  "
+                         "both (default) = torch, with the same number of predict-only steps timed in front of the "
+                         "timed steps in the same launch (phases.predict_only), so that ONE run yields the split")
     ap.add_argument("--rows", type=int, default=0,
                     help="use only the first N rows of the grid's batch (tests of ragged shards: N % gpus != 0)")
     ap.add_argument("--path", default="rows", choices=["rows", "fields", "run1"],
@@ -650,7 +658,9 @@ def main():
     waves_per_cu = 16 if "ring" in booster.kernel_symbol(27) else 20
     reserve = int({kv.partition("=")[0]: kv.partition("=")[2] for kv in args.param}.get("ohx_reserve_cus", 0)) if waves_per_cu == 16 else 0
     round_rows = (torch.cuda.get_device_properties(dev).multi_processor_count - reserve) * waves_per_cu * 64
-    pieces = shard.plan_pieces(n_local, args.gather_chunks if (gather and even) else 1, granule, round_rows, world)
+    prices = shard.price_list(args.gather_gbps, args.piece_rounds)
+    pieces, plan_table = shard.plan_pieces_priced(n_local, args.gather_chunks if (gather and even) else 1, granule,
+                                                  round_rows, world, prices)
     dmats = [capi.DMatrix(device_ptr=rows.data_ptr() + lo * synth.NFEAT * 4, nrow=hi - lo, ncol=synth.NFEAT,
                           missing=synth.XX_MISS) for lo, hi in pieces]
     if use_grid:
@@ -669,6 +679,7 @@ def main():
 
     chunks = shard.ChunkGather(out_full, n_local, world, pieces) if (gather and len(pieces) > 1) else None
     native = None
+    control_loop = gather and args.gather == "both"
     if gather and args.gather == "native":
         # the C-ABI route a Fortran/MPI host would take (include/ohxgb.h part 4): RCCL through libohxgb.so itself;
         # the 128-byte id travels over torch.distributed here, over MPI_Bcast there
@@ -676,15 +687,19 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         native = capi.Communicator(ids[0], world, rank)
 
-    def step(i=None):
+    def step(i=None, with_gather=True, e0=None, e1=None):
+        e0 = ev0 if e0 is None else e0
+        e1 = ev1 if e1 is None else e1
         if i is not None:
-            ev0[i].record(stream)
+            e0[i].record(stream)
         for q, ((lo, hi), dm) in enumerate(zip(pieces, dmats)):
             booster.predict_device(dm, out_local.data_ptr() + lo * 4, stream=stream.cuda_stream)
-            if chunks is not None and native is None:
+            if with_gather and chunks is not None and native is None:
                 chunks.start(q, out_local)
         if i is not None:
-            ev1[i].record(stream)      # with N > 1 this spans the predict launches of all pieces
+            e1[i].record(stream)      # with N > 1 this spans the predict launches of all pieces
+        if not with_gather:
+            return
         if native is not None:
             native.all_gather_oh(out_local.data_ptr(), n_local, n_total, out_full.data_ptr(), stream=stream.cuda_stream)
         elif chunks is not None:
@@ -700,6 +715,19 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # --gather both: the same K steps without the all-gather, in front of the timed ones (in effect K more warm-up
+    # steps): what the gather costs is then the difference of two loops of ONE launch, on the same ranks and clocks
+    control = None
+    if control_loop:
+        c0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        c1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, with_gather=False, e0=c0, e1=c1)
+        fence()
+        control = [(time.perf_counter() - t0) / args.steps * 1e3,
+                   float(np.mean([a.elapsed_time(b) for a, b in zip(c0, c1)]))]
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -707,6 +735,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     booster.check()
+    my_step_ms = elapsed / args.steps * 1e3
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -735,6 +764,12 @@ def main():
             raise SystemExit("bench: the timed output differs from the cross-check kernel's (or the gathered field is misplaced)")
     kernel_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
     kernel_s = float(np.mean(kernel_ms)) * 1e-3
+    # every rank's two numbers on every rank (and the control loop's): `phases` prints them per rank
+    per_rank = control_by_rank = rows_by_rank = None
+    if world > 1 or force_dist:
+        per_rank = shard.rank_times([my_step_ms, kernel_s * 1e3])
+        control_by_rank = shard.rank_times(control) if control is not None else None
+        rows_by_rank = [shard.row_shard(n_total, world, r)[1] for r in range(world)]
     if world > 1:
         t = torch.tensor([kernel_s], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -810,13 +845,12 @@ def main():
                                      "(cpu_baseline.margins_bit_identical_on_first_rows / _on_random_rows)") if verified else None,
                 "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
                 "gather_via": (args.gather if (world > 1 or force_dist) else None),
+                "planner_prices": prices if (world > 1 or force_dist) else None,
             },
             # N > 1: where a step's time goes.  predict_ms = first launch to last launch of the rank's pieces (events
             # on the launching stream, max over ranks); exposed_gather_ms = what the step takes beyond that: the part
             # of the all-gather (and of the copies into place) that the prediction of the next piece does not hide
-            "phases": ({"predict_ms": kernel_s * 1e3, "exposed_gather_ms": ms_per_step - kernel_s * 1e3,
-                        "gather_bytes_per_rank_sent": 4 * n_local, "gather_bytes_total": 4 * n_total,
-                        "pieces": [hi - lo for lo, hi in pieces], "even_shards": even}
+            "phases": (shard.phases_record(per_rank, rows_by_rank, n_total, pieces, even, plan_table, prices, control_by_rank)
                        if (world > 1 or force_dist) else None),
             "distributed": dist_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

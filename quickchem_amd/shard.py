@@ -62,35 +62,51 @@ def chunk_bounds(n_local: int, nchunks: int, granule: int) -> list:
     return out
 
 
-# plan_pieces' price list, in rounds of the chip (one residency's rows walked through the OH booster, ~0.11 ms on an MI355X):
+# plan_pieces' price list, in rounds of the chip (one residency's rows walked through the OH booster, ~0.11 ms on an MI355X).
+# GATHER_BYTES_PER_S and PIECE_ROUNDS are guesses no N > 1 run has confirmed: bench.py takes them
+# from --gather-gbps / --piece-rounds (or OHX_GATHER_GBPS / OHX_PIECE_ROUNDS in the environment), echoes what it used
+# and prints every plan it priced, so that the first 8-GPU line can be re-planned from what it measured.
 WALK_ROWS_PER_S = 2.3e9          # bench.py, C360 step
-GATHER_BYTES_PER_S = 100e9       # what one rank takes in during an all-gather over xGMI - a guess on the safe side, no
-                                 # N > 1 run has been measured
+GATHER_BYTES_PER_S = 100e9       # what one rank takes in during an all-gather over xGMI - a guess on the safe side
 PIECE_ROUNDS = 0.4               # one more launch, one more collective enqueued: 40-45 us a piece, measured on a C360/8 shard
                                  # with one-rank RCCL (profiles/r04_sweeps.txt)
 
 
-def plan_pieces(n_local: int, max_pieces: int, granule: int, round_rows: int, world: int = 1) -> list:
-    """Cut [0, n_local) into at most `max_pieces` pieces of whole granules (a grid level when the
-    waves take bricks) so that the pieces' all-gathers can overlap the next piece's prediction.
-    A piece occupies the GPU for ceil(rows / round_rows) rounds (round_rows = rows one residency of
-    the chip covers).  world <= 1 (nothing to gather, or unknown): the plan with the fewest rounds
-    wins and, among equals, the one with the most pieces.  world > 1: every plan is priced in
-    rounds - its own, plus the all-gather of its LAST piece, which nothing hides (rows x 4 B x
-    (world - 1) at GATHER_BYTES_PER_S), plus PIECE_ROUNDS per piece - and the cheapest wins: an
-    extra round is worth paying when it shrinks what stays exposed (C360 on 2 GPUs: one piece of 36
-    levels would leave 112 MB per rank unhidden; four of 9 cost one round more of 107)."""
+def price_list(gather_gbps=None, piece_rounds=None, environ=None) -> dict:
+    """The two guessed prices: argument, else environment (OHX_GATHER_GBPS, OHX_PIECE_ROUNDS), else the module's."""
+    import os
+    env = os.environ if environ is None else environ
+    g = gather_gbps if gather_gbps is not None else (float(env["OHX_GATHER_GBPS"]) if env.get("OHX_GATHER_GBPS") else None)
+    q = piece_rounds if piece_rounds is not None else (float(env["OHX_PIECE_ROUNDS"]) if env.get("OHX_PIECE_ROUNDS") else None)
+    out = {"gather_bytes_per_s": GATHER_BYTES_PER_S if g is None else g * 1e9,
+           "piece_rounds": PIECE_ROUNDS if q is None else q,
+           "walk_rows_per_s": WALK_ROWS_PER_S,
+           "source": {"gather_bytes_per_s": "default (a guess)" if g is None else "given",
+                      "piece_rounds": "default (one-rank RCCL)" if q is None else "given"}}
+    if out["gather_bytes_per_s"] <= 0 or out["piece_rounds"] < 0:
+        raise ValueError("gather GB/s must be positive and rounds per piece not negative")
+    return out
+
+
+def plan_pieces_priced(n_local: int, max_pieces: int, granule: int, round_rows: int, world: int = 1, prices=None):
+    """plan_pieces, and the table it chose from: -> (pieces, [{"pieces", "sizes", "rounds", "exposed_rounds",
+    "cost_rounds", "chosen"}]).  `prices` = price_list(...)."""
+    prices = prices or price_list(environ={})
+    gbs, per_piece, walk = prices["gather_bytes_per_s"], prices["piece_rounds"], prices["walk_rows_per_s"]
     if max_pieces <= 1 or granule <= 0 or n_local <= granule:
-        return [(0, n_local)]
+        return [(0, n_local)], [{"pieces": 1, "sizes": [n_local], "rounds": -(-n_local // round_rows) if round_rows else 0,
+                                 "exposed_rounds": None, "cost_rounds": None, "chosen": True}]
     units = -(-n_local // granule)
 
     def exposed(last_rows):
         if world <= 1:
             return 0.0
-        return last_rows * 4.0 * (world - 1) / GATHER_BYTES_PER_S / (round_rows / WALK_ROWS_PER_S)
+        return last_rows * 4.0 * (world - 1) / gbs / (round_rows / walk)
 
     best, best_rounds = [(0, n_local)], -(-n_local // round_rows)
-    best_cost = best_rounds + exposed(n_local) + PIECE_ROUNDS
+    best_cost = best_rounds + exposed(n_local) + per_piece
+    table = [{"pieces": 1, "sizes": [n_local], "rounds": best_rounds, "exposed_rounds": exposed(n_local),
+              "cost_rounds": best_cost}]
     for k in range(2, min(max_pieces, units) + 1):
         base, rem = divmod(units, k)
         sizes = [(base + (1 if q < rem else 0)) * granule for q in range(k)]
@@ -100,14 +116,66 @@ def plan_pieces(n_local: int, max_pieces: int, granule: int, round_rows: int, wo
             out.append((lo, hi))
             lo = hi
         rounds = sum(-(-(hi - lo) // round_rows) for lo, hi in out)
+        cost = rounds + exposed(out[-1][1] - out[-1][0]) + per_piece * k
+        table.append({"pieces": k, "sizes": [hi - lo for lo, hi in out], "rounds": rounds,
+                      "exposed_rounds": exposed(out[-1][1] - out[-1][0]), "cost_rounds": cost})
         if world <= 1:
             if rounds <= best_rounds:
                 best, best_rounds = out, rounds
-        else:
-            cost = rounds + exposed(out[-1][1] - out[-1][0]) + PIECE_ROUNDS * k
-            if cost < best_cost - 1e-9:
-                best, best_cost = out, cost
-    return best
+        elif cost < best_cost - 1e-9:
+            best, best_cost = out, cost
+    for row in table:
+        row["chosen"] = row["pieces"] == len(best)
+    return best, table
+
+
+def plan_pieces(n_local: int, max_pieces: int, granule: int, round_rows: int, world: int = 1, prices=None) -> list:
+    """Cut [0, n_local) into at most `max_pieces` pieces of whole granules (a grid level when the
+    waves take bricks) so that the pieces' all-gathers can overlap the next piece's prediction.
+    A piece occupies the GPU for ceil(rows / round_rows) rounds (round_rows = rows one residency of
+    the chip covers).  world <= 1 (nothing to gather, or unknown): the plan with the fewest rounds
+    wins and, among equals, the one with the most pieces.  world > 1: every plan is priced in
+    rounds - its own, plus the all-gather of its LAST piece, which nothing hides (rows x 4 B x
+    (world - 1) at the gather rate of `prices`), plus a price per piece - and the cheapest wins: an
+    extra round is worth paying when it shrinks what stays exposed (C360 on 2 GPUs: one piece of 36
+    levels would leave 112 MB per rank unhidden; four of 9 cost one round more of 107)."""
+    return plan_pieces_priced(n_local, max_pieces, granule, round_rows, world, prices)[0]
+
+
+def rank_times(values) -> list:
+    """Every rank's list of numbers, on every rank, in rank order (all_gather_object: works on gloo and on RCCL):
+    what bench.py's `phases` prints per rank, so that a straggler or a mis-planned split shows in the first N > 1 line."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [list(map(float, values))]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, list(map(float, values)))
+    return out
+
+
+def phases_record(per_rank, n_local_by_rank, n_total, pieces, even, plan_table, prices, control=None) -> dict:
+    """bench.py's `phases` object.  per_rank[r] = [step_ms, predict_ms] of rank r's timed loop (predict = first launch to
+    last launch of its pieces, events on the launching stream); control[r] = the same two from a loop WITHOUT the gather
+    (--gather both), or None.  exposed_gather_ms[r] = step - predict: what of the all-gather and of the copies into place
+    the prediction of the next piece did not hide on rank r."""
+    step = [r[0] for r in per_rank]
+    pred = [r[1] for r in per_rank]
+    rec = {
+        "predict_ms": max(pred), "exposed_gather_ms": max(step) - max(pred),
+        "per_rank": {"step_ms": step, "predict_ms": pred, "exposed_gather_ms": [s - p for s, p in zip(step, pred)],
+                     "rows": list(n_local_by_rank)},
+        "slowest_rank": {"step": step.index(max(step)), "predict": pred.index(max(pred))},
+        "gather_bytes_per_rank_sent": [4 * n for n in n_local_by_rank], "gather_bytes_total": 4 * n_total,
+        "pieces": [hi - lo for lo, hi in pieces], "even_shards": even,
+        "plan": {"prices": prices, "priced": plan_table},
+        "hardware_note": "no claim: what an N > 1 run says about xGMI is only known once one has run",
+    }
+    if control is not None:
+        cstep = [r[0] for r in control]
+        cpred = [r[1] for r in control]
+        rec["predict_only"] = {"step_ms": max(cstep), "per_rank_step_ms": cstep, "per_rank_predict_ms": cpred,
+                               "what": "the same steps with the all-gather left out, timed in the same launch"}
+        rec["gather_costs_ms"] = max(step) - max(cstep)
+    return rec
 
 
 class ChunkGather:

@@ -57,6 +57,44 @@ def test_plan_pieces_prices_the_gather_nothing_hides():
     assert shard.plan_pieces(plane, 6, plane, rr, 8) == [(0, plane)]
 
 
+def test_the_planner_prices_can_be_given_and_every_priced_plan_is_reported():
+    """the two guessed prices are not compiled in any more - argument, else environment, else default -
+    and plan_pieces_priced returns the table the choice was made from, so a measured 8-GPU line can be re-planned."""
+    d = shard.price_list(environ={})
+    assert d["gather_bytes_per_s"] == shard.GATHER_BYTES_PER_S and d["piece_rounds"] == shard.PIECE_ROUNDS
+    assert "guess" in d["source"]["gather_bytes_per_s"]
+    e = shard.price_list(environ={"OHX_GATHER_GBPS": "40", "OHX_PIECE_ROUNDS": "1.5"})
+    assert e["gather_bytes_per_s"] == 40e9 and e["piece_rounds"] == 1.5 and e["source"]["piece_rounds"] == "given"
+    assert shard.price_list(250.0, 0.1, environ={"OHX_GATHER_GBPS": "40"})["gather_bytes_per_s"] == 250e9     # argument first
+    with pytest.raises(ValueError):
+        shard.price_list(0.0, None, environ={})
+    plane, rr = 360 * 2160, 256 * 16 * 64
+    n = 9 * plane
+    best, table = shard.plan_pieces_priced(n, 6, plane, rr, 8, d)
+    assert best == shard.plan_pieces(n, 6, plane, rr, 8) and [r["pieces"] for r in table] == [1, 2, 3, 4, 5, 6]
+    assert sum(r["chosen"] for r in table) == 1 and [r for r in table if r["chosen"]][0]["sizes"] == [hi - lo for lo, hi in best]
+    assert all(abs(r["cost_rounds"] - (r["rounds"] + r["exposed_rounds"] + d["piece_rounds"] * r["pieces"])) < 1e-9 for r in table)
+    assert min(table, key=lambda r: r["cost_rounds"])["chosen"]
+    # a slow link makes small last pieces worth more launches, a dear piece fewer of them
+    slow = shard.plan_pieces(n, 6, plane, rr, 8, shard.price_list(10.0, 0.4, environ={}))
+    dear = shard.plan_pieces(n, 6, plane, rr, 8, shard.price_list(100.0, 5.0, environ={}))
+    assert len(slow) >= len(best) >= len(dear) and len(dear) < len(slow)
+
+
+def test_phases_record_shows_every_rank():
+    """bench.py's `phases`: per-rank step and predict times, the exposed part of the gather per rank, who was slowest,
+    the control loop without the gather (--gather both) and what the gather costs by that."""
+    pieces = [(0, 100), (100, 160)]
+    rec = shard.phases_record([[10.0, 8.0], [12.5, 8.5]], [160, 160], 320, pieces, True, [{"pieces": 2, "chosen": True}],
+                              shard.price_list(environ={}), control=[[8.2, 8.0], [8.9, 8.5]])
+    assert rec["per_rank"]["step_ms"] == [10.0, 12.5] and rec["per_rank"]["exposed_gather_ms"] == [2.0, 4.0]
+    assert rec["slowest_rank"] == {"step": 1, "predict": 1} and rec["predict_ms"] == 8.5 and rec["exposed_gather_ms"] == 4.0
+    assert rec["predict_only"]["step_ms"] == 8.9 and abs(rec["gather_costs_ms"] - 3.6) < 1e-9
+    assert rec["pieces"] == [100, 60] and rec["gather_bytes_per_rank_sent"] == [640, 640] and rec["gather_bytes_total"] == 1280
+    assert "predict_only" not in shard.phases_record([[1.0, 1.0]], [5], 5, [(0, 5)], True, [], shard.price_list(environ={}))
+    assert shard.rank_times([1, 2.5]) == [[1.0, 2.5]]                 # no process group: this process alone
+
+
 def test_chunk_bounds_cover_the_shard():
     for n_local in (1, 639, 640, 641, 6_998_400, 53_265_600):
         for k in (1, 2, 4, 7):
@@ -101,6 +139,8 @@ def _worker(rank, world, port, n_total, image_path, out_dir):
                 gather.start(q, local)
             gather.finish()
             assert torch.equal(full2.view(torch.int32), full.view(torch.int32))
+        # what bench.py's `phases` is made of: every rank's numbers on every rank, in rank order
+        assert shard.rank_times([rank + 0.5, 10 * rank]) == [[r + 0.5, 10.0 * r] for r in range(world)]
         # the C ABI's shard rule is the Python one (OHXShardRows: what a Fortran/MPI host would call)
         from quickchem_amd import capi
         for r in range(world):

@@ -222,6 +222,13 @@ def test_two_ranks_share_the_gpu_and_agree_with_one(tmp_path):
         assert line["config"]["verified"] is True and line["n_gpus"] == 2 and line["config"]["grid_hint"] is True
         assert line["phases"]["even_shards"] is True and line["phases"]["gather_bytes_total"] == 4 * 90 * 540 * 72
         assert line["phases"]["predict_ms"] > 0 and len(line["distributed"]["ranks"]) == 2
+        # (r5) the line explains itself: both ranks' numbers, the control loop without the gather, the priced plans
+        ph = line["phases"]
+        assert line["config"]["gather_via"] == "both" and len(ph["per_rank"]["step_ms"]) == 2
+        assert len(ph["per_rank"]["predict_ms"]) == 2 and ph["per_rank"]["rows"] == [90 * 540 * 36] * 2
+        assert ph["predict_only"]["step_ms"] > 0 and len(ph["predict_only"]["per_rank_step_ms"]) == 2
+        assert ph["plan"]["prices"]["gather_bytes_per_s"] == 100e9 and sum(r["chosen"] for r in ph["plan"]["priced"]) == 1
+        assert [r for r in ph["plan"]["priced"] if r["chosen"]][0]["sizes"] == ph["pieces"]
     # under torch.distributed.run (the other way to start it): ragged shards (an odd number of rows over two ranks:
     # the fixed-slot gather and its compaction), and the predict-only control that a scaling curve is split with
     for extra in (["--rows", "995327"], ["--gather", "none"]):
@@ -248,9 +255,9 @@ def test_bench_over_rccl_with_one_rank():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OHX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
-    for gather in ("torch", "native", "none"):
+    for gather in ("both", "torch", "native", "none"):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--grid", "C90", "--steps", "2",
-                            "--warmup", "1", "--cpu-seconds", "0", "--gather", gather],
+                            "--warmup", "1", "--cpu-seconds", "0", "--gather", gather, "--gather-gbps", "60"],
                            capture_output=True, text=True, env=env, timeout=900, cwd=root)
         assert r.returncode == 0, (gather, r.stdout[-1500:], r.stderr[-3000:])
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -261,6 +268,7 @@ def test_bench_over_rccl_with_one_rank():
         ph = line["phases"]
         assert ph["predict_ms"] > 0 and ph["gather_bytes_total"] == 4 * 90 * 540 * 72
         assert line["config"]["gather_pieces"] == (0 if gather == "none" else len(ph["pieces"]))
+        assert line["config"]["planner_prices"]["gather_bytes_per_s"] == 60e9 and ("predict_only" in ph) == (gather == "both")
 
 
 def test_native_all_gather_entry_points_on_one_rank():
