@@ -29,11 +29,13 @@
     }                                                                               \
   } while (0)
 
-enum Kind { K_ADD = 0, K_FMA, K_CMP, K_CNDMASK, K_ADDC, K_ADDLSHL, K_WALK, K_COUNT };
+enum Kind { K_ADD = 0, K_FMA, K_CMP, K_CNDMASK, K_ADDC, K_ADDLSHL, K_WALK, K_CMP32, K_CNDMASK32, K_ADDC32, K_WALK32, K_COUNT };
 static const char* kKindName[K_COUNT] = {"v_add_u32", "v_fma_f32", "v_cmp_lt_f32(e64)", "v_cndmask_b32(e64)",
-                                         "v_addc_co_u32", "v_add_lshl_u32", "walk-step x4 chains"};
+                                         "v_addc_co_u32", "v_add_lshl_u32", "walk-step x4 chains",
+                                         "v_cmp_lt_f32_e32 vcc", "v_cndmask_b32_e32 vcc", "v_addc_co_u32_e32 vcc",
+                                         "walk-step, vcc forms"};
 // vector instructions per loop trip, per kind
-static const int kPerTrip[K_COUNT] = {32, 32, 32, 32, 32, 32, 56};
+static const int kPerTrip[K_COUNT] = {32, 32, 32, 32, 32, 32, 56, 32, 32, 32, 56};
 
 // One block = 256 threads = one wave per SIMD.  `iters` trips of a straight-line body of independent (or, for
 // K_WALK, chain-dependent) instructions; s_memtime around the loop, per wave.
@@ -105,6 +107,73 @@ __global__ __launch_bounds__(256) void valu_kernel(int iters, uint32_t seed, uin
             "v_add_lshl_u32 %6, %6, %8, 4\n v_add_lshl_u32 %7, %7, %8, 4\n"
             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
             : "v"(b));
+    } else if (KIND == K_CMP32) {
+      // the 4-byte encodings (VOPC / VOP2 with the mask in VCC) of the same three instructions: what the step could be
+      // written in, chain by chain (r5: an 8-byte VOP3 costs a SIMD 4.3-4.5 cycles, a 4-byte v_add_u32 2.8)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        asm volatile(
+            "v_cmp_lt_f32_e32 vcc, %0, %4\n v_cmp_lt_f32_e32 vcc, %1, %4\n"
+            "v_cmp_lt_f32_e32 vcc, %2, %4\n v_cmp_lt_f32_e32 vcc, %3, %4\n"
+            : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)
+            : "v"(fb)
+            : "vcc");
+    } else if (KIND == K_CNDMASK32) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        asm volatile(
+            "v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n"
+            "v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n"
+            "v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n"
+            "v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+            : "v"(b)
+            : "vcc");
+    } else if (KIND == K_ADDC32) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        asm volatile(
+            "v_addc_co_u32_e32 %0, vcc, %0, %8, vcc\n v_addc_co_u32_e32 %1, vcc, %1, %8, vcc\n"
+            "v_addc_co_u32_e32 %2, vcc, %2, %8, vcc\n v_addc_co_u32_e32 %3, vcc, %3, %8, vcc\n"
+            "v_addc_co_u32_e32 %4, vcc, %4, %8, vcc\n v_addc_co_u32_e32 %5, vcc, %5, %8, vcc\n"
+            "v_addc_co_u32_e32 %6, vcc, %6, %8, vcc\n v_addc_co_u32_e32 %7, vcc, %7, %8, vcc\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+            : "v"(b)
+            : "vcc");
+    } else if (KIND == K_WALK32) {
+      // the same 14 instructions per chain with every mask in VCC: block A (compare at the node, the child's threshold
+      // and shift selected, the group index doubled with the decision carried in), the two VOP3 that have no short
+      // form (v_bfe_u32, v_lshl_add_u32), block B (compare at the child, second doubling, leaf test, leaf kept),
+      // v_add_lshl_u32; chain after chain - within a block the mask lives in VCC, so blocks do not interleave; with the
+      // two wait states gfx940+ wants between a VALU writing VCC and a VALU reading it (s_nop: not vector instructions)
+      uint32_t t0_, t1_, t2_, t3_, t4_, t5_, t6_, t7_, t8_, t9_, t10_, t11_, t12_, t13_, t14_, t15_;
+#define W32(A, F, T0, T1, T2, T3)                                                         \
+  "v_cmp_nlt_f32_e32 vcc, %" F ", %25\n"                                                  \
+  "v_lshrrev_b32_e32 %" T3 ", 18, %" A "\n"                                               \
+  "s_nop 0\n"                                                                             \
+  "v_cndmask_b32_e32 %" T1 ", %" A ", %24, vcc\n"                                          \
+  "v_cndmask_b32_e32 %" T0 ", 0, %24, vcc\n"                                              \
+  "v_addc_co_u32_e32 %" T3 ", vcc, %" T3 ", %" T3 ", vcc\n"                                \
+  "v_bfe_u32 %" T2 ", %" A ", %" T0 ", 5\n"                                               \
+  "v_lshl_add_u32 %" T0 ", %" T2 ", 8, %24\n"                                             \
+  "v_cmp_nlt_f32_e32 vcc, %" F ", %25\n"                                                  \
+  "s_nop 1\n"                                                                             \
+  "v_addc_co_u32_e32 %" T3 ", vcc, %" T3 ", %" T3 ", vcc\n"                                \
+  "v_cmp_eq_u32_e32 vcc, 31, %" T2 "\n"                                                   \
+  "s_nop 1\n"                                                                             \
+  "v_cndmask_b32_e32 %" F ", %" F ", %25, vcc\n"                                           \
+  "v_and_b32_e32 %" T1 ", 0x1f00, %" T1 "\n"                                              \
+  "v_add_lshl_u32 %" A ", %" T3 ", %24, 4\n"                                              \
+  "v_xor_b32_e32 %" A ", %" A ", %" T1 "\n"
+      asm volatile(W32("0", "4", "8", "9", "10", "11") W32("1", "5", "12", "13", "14", "15") W32("2", "6", "16", "17", "18", "19")
+                       W32("3", "7", "20", "21", "22", "23")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "=&v"(t0_), "=&v"(t1_),
+                     "=&v"(t2_), "=&v"(t3_), "=&v"(t4_), "=&v"(t5_), "=&v"(t6_), "=&v"(t7_), "=&v"(t8_), "=&v"(t9_),
+                     "=&v"(t10_), "=&v"(t11_), "=&v"(t12_), "=&v"(t13_), "=&v"(t14_), "=&v"(t15_)
+                   : "v"(b), "v"(fb)
+                   : "vcc");
+#undef W32
+      a4 ^= t2_ ^ t6_ ^ t10_ ^ t14_;
     } else {
       // the ring kernel's two-level step without its LDS read and its gather, per chain 14 vector instructions:
       // bfe (feature row), 3 compares, 2 mask selects of child data, leaf test + keep (cmp, cndmask), the record
@@ -190,7 +259,8 @@ __global__ __launch_bounds__(256) void valu_kernel(int iters, uint32_t seed, uin
 
 typedef void (*kernel_t)(int, uint32_t, uint32_t*, unsigned long long*);
 static kernel_t kKernels[K_COUNT] = {valu_kernel<K_ADD>,     valu_kernel<K_FMA>,  valu_kernel<K_CMP>, valu_kernel<K_CNDMASK>,
-                                     valu_kernel<K_ADDC>,    valu_kernel<K_ADDLSHL>, valu_kernel<K_WALK>};
+                                     valu_kernel<K_ADDC>,    valu_kernel<K_ADDLSHL>, valu_kernel<K_WALK>, valu_kernel<K_CMP32>,
+                                     valu_kernel<K_CNDMASK32>, valu_kernel<K_ADDC32>, valu_kernel<K_WALK32>};
 
 int main(int argc, char** argv) {
   int only = -1, only_w = -1, iters = 20000;
