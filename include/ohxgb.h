@@ -104,6 +104,9 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *   "ohx_reserve_cus" ring kernels (rows): compute units left free, 0..128 (default 0).  A ring block owns its CU for the
  *                     length of a launch; a collective enqueued beside the predict (OHXAllGatherOH, torch.distributed)
  *                     otherwise only gets on the chip at a launch boundary
+ *   "ohx_run1_pieces" OHXBoosterRun1[Device] on a slab of several launches of the ring kernel: ranges of j walked one after
+ *                     the other, with the feature engineering of the next and the post-processing of the last on a
+ *                     second stream beside the walk; 0 = as many as pay (default), 1 = one piece, n = n pieces
  *   "ohx_register_host"  0 | 1, process-wide (the handle may be NULL): the host arrays handed to OHXBoosterRun1,
  *                     OHXOHPostProcess and OHXBoosterPredictFields are registered with the GPU driver the first time
  *                     they are seen and moved by DMA - a rank-sized block's forty arrays by ONE copy launch - from

@@ -409,6 +409,11 @@ struct BoosterObj {
   ~BoosterObj() {
     if (s_copy) (void)hipStreamDestroy(s_copy);
     if (s_exec) (void)hipStreamDestroy(s_exec);
+    if (s_run1) (void)hipStreamDestroy(s_run1);
+    for (hipEvent_t e : {run1_fork, run1_slab, run1_join})
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : run1_prep) (void)hipEventDestroy(e);
+    for (hipEvent_t e : run1_walk) (void)hipEventDestroy(e);
     if (train.side) (void)hipStreamDestroy(train.side);
     if (train.fork) (void)hipEventDestroy(train.fork);
     if (train.join) (void)hipEventDestroy(train.join);
@@ -453,6 +458,12 @@ struct BoosterObj {
   DevBuf<float> d_pred;
   PinnedBuf<float> h_pred;
   hipStream_t s_copy = nullptr, s_exec = nullptr;   // fused host path: PCIe copies beside the kernels
+  // OH Run1 (run1_device): the slab count, and the streaming kernels of the pieces that are not being walked, run on a
+  // side stream beside the caller's
+  hipStream_t s_run1 = nullptr;
+  hipEvent_t run1_fork = nullptr, run1_slab = nullptr, run1_join = nullptr;
+  std::vector<hipEvent_t> run1_prep, run1_walk;
+  PinnedBuf<int32_t> h_slab;
   std::vector<DevBuf<float>> d_stage;  // fused host path: per-field staging
   DevBuf<float> d_stage_out, d_stage_margin;
   // Run1: engineered features, OH_ML and the slab result stay in HBM between the steps
@@ -1264,6 +1275,10 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     const int k = atoi(value);
     if (k < 0) throw OhxError("ohx_ring_rounds must be >= 0");
     b->tune.ring_rounds = k;
+  } else if (n == "ohx_run1_pieces") {
+    const int k = atoi(value);
+    if (k < 0 || k > 64) throw OhxError("ohx_run1_pieces must be 0 (auto) .. 64");
+    b->tune.run1_pieces = k;
   } else if (n == "ohx_tree_split") {
     if (v == "auto") b->tune.tree_split = -1;
     else if (v == "off") b->tune.tree_split = 0;
@@ -1526,6 +1541,57 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   float* oh_ml = or_scratch(r.oh_boost, 8);
   float* aod = or_scratch(r.diag_aod, 9);
 
+  // ---- How a tick is laid out on the GPU (r5).  Two streams: the caller's, and a side stream of the booster's.
+  //   side:   slab count (needs PLE and TROPP only) -> OH_ML := 0 -> [features of piece 1] -> after the walk of piece 0:
+  //           post-processing of piece 0, [features of piece 2] -> ...
+  //   main:   features of piece 0 -> (the host reads the slab count) -> walk of piece 0 -> walk of piece 1 -> ...
+  // A PIECE is a range of j of the grid, all levels: the column sums need whole columns, the walk needs every feature
+  // of the cells it walks, the mask and the unit conversion need the walk's OH_ML - and none of them needs another
+  // column.  So of the streaming kernels (pointwise features, column sums, slab count, post-processing: 1.3 ms of a
+  // C360 tick's 20.2 when they ran one after the other around the walk) only the first piece's features and the last
+  // piece's post-processing are not hidden behind a walk, which leaves the CUs' spare registers and the whole of HBM's
+  // bandwidth to them.  A slab of fewer than two launches of the ring kernel (a rank's block) is one piece.
+  if (!b.s_run1) {
+    HIP_CHECK(hipStreamCreateWithFlags(&b.s_run1, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&b.run1_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&b.run1_slab, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&b.run1_join, hipEventDisableTiming));
+  }
+  b.h_slab.ensure(2);
+  hipStream_t side = b.s_run1;
+  HIP_CHECK(hipEventRecord(b.run1_fork, stream));            // the side stream starts behind what the caller has enqueued
+  HIP_CHECK(hipStreamWaitEvent(side, b.run1_fork, 0));
+
+  SlabArgs sa;
+  sa.im = r.im; sa.jm = r.jm; sa.km = r.km;
+  sa.dynamic_k_range = r.dynamic_k_range; sa.tropp_min = r.tropp_min;
+  sa.ple_mod = r.ple_mod; sa.tropp = r.tropp_mod; sa.result = b.d_slab.p;
+  HIP_CHECK(hipMemsetAsync(b.d_slab.p, 0, 2 * sizeof(int32_t), side));
+  HIP_CHECK(launch_k_slab(sa, side));
+  HIP_CHECK(hipMemcpyAsync(b.h_slab.p, b.d_slab.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, side));
+  HIP_CHECK(hipEventRecord(b.run1_slab, side));
+  HIP_CHECK(hipMemsetAsync(oh_ml, 0, vol * sizeof(float), side));            // self%OH_ML(:,:,:) = 0.0 (:1559)
+
+  // pieces: as many as the slab's tiles make whole launches of the ring kernel (at its most, all km levels), of whole
+  // rows of bricks (four j); the pieces' extents do not depend on the slab count, which is not known yet
+  const KernelKind kind = pick_kernel(b);
+  int npieces = 1;
+  if (kind == KernelKind::Ring && b.tune.run1_pieces != 1) {
+    const uint64_t per_launch = (uint64_t)b.dev.num_cus * 16u * (uint64_t)std::max(1, b.tune.ring_rounds) * 64u;   // rows
+    const uint64_t most = (uint64_t)vol;
+    npieces = b.tune.run1_pieces > 1 ? b.tune.run1_pieces : (int)std::min<uint64_t>(8, most / per_launch);
+    npieces = std::max(1, std::min(npieces, r.jm / 8));
+  }
+  std::vector<int> j_lo((size_t)npieces + 1, 0);
+  for (int q = 1; q <= npieces; ++q) j_lo[(size_t)q] = q == npieces ? r.jm : (int)((int64_t)r.jm * q / npieces / 4 * 4);
+  while (b.run1_prep.size() < (size_t)npieces) {
+    hipEvent_t e1, e2;
+    HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    b.run1_prep.push_back(e1);
+    b.run1_walk.push_back(e2);
+  }
+
   PrepArgs pa;
   pa.im = r.im; pa.jm = r.jm; pa.km = r.km;
   pa.ple_bst = r.ple_bst; pa.zle_bst = r.zle_bst; pa.tauclw = r.tauclw; pa.taucli = r.taucli;
@@ -1533,59 +1599,100 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   pa.gmito3 = r.gmito3; pa.gmitto3 = r.gmitto3;
   pa.pl_bst = pl_bst; pa.tauclwdn = tauclwdn; pa.tauclidn = tauclidn; pa.taucliup = taucliup; pa.tauclwup = tauclwup;
   pa.aodup = aodup; pa.aoddn = aoddn; pa.strato3 = strato3;
-  HIP_CHECK(launch_feature_prep(pa, aod, stream));
-
-  SlabArgs sa;
-  sa.im = r.im; sa.jm = r.jm; sa.km = r.km;
-  sa.dynamic_k_range = r.dynamic_k_range; sa.tropp_min = r.tropp_min;
-  sa.ple_mod = r.ple_mod; sa.tropp = r.tropp_mod; sa.result = b.d_slab.p;
-  HIP_CHECK(hipMemsetAsync(b.d_slab.p, 0, 2 * sizeof(int32_t), stream));
-  HIP_CHECK(launch_k_slab(sa, stream));
-  int32_t slab[2] = {0, 0};
-  HIP_CHECK(hipMemcpyAsync(slab, b.d_slab.p, sizeof slab, hipMemcpyDeviceToHost, stream));
-  HIP_CHECK(hipStreamSynchronize(stream));
-  if (!r.dynamic_k_range && slab[1] != 0)
-    throw OhxError("OH Prediction: Minimum tropopause pressure is not low enough!");
-  const int k1 = r.km - slab[0] + 1, k2 = r.km;   // 1-based (:300-301)
-  if (r.k1) *r.k1 = k1;
-  if (r.k2) *r.k2 = k2;
-
-  HIP_CHECK(hipMemsetAsync(oh_ml, 0, vol * sizeof(float), stream));          // self%OH_ML(:,:,:) = 0.0 (:1559)
-  const float* fields[27] = {r.lat_deg, pl_bst, r.t_bst, r.no2, r.o3, r.ch4, r.co, r.isop, r.acet, r.c2h6, r.c3h8,
-                             r.prpe, r.alk4, r.mp, r.h2o2, tauclwdn, tauclidn, taucliup, tauclwup, r.cloud, r.qv,
-                             strato3, r.albuv, aodup, aoddn, r.ch2o, r.sza};      // order of :313-339
-  static const int32_t is2d[27] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};
-  if (k2 >= k1) {
-    FieldsArgs fa{};
-    fa.is2d_mask = 0;
-    for (int f = 0; f < 27; ++f) {
-      fa.field[f] = fields[f];
-      if (is2d[f]) fa.is2d_mask |= (1u << f);
+  auto prep_piece = [&](int q, hipStream_t s) {
+    PrepArgs p = pa;
+    if (npieces > 1) {
+      p.col0 = (uint64_t)j_lo[(size_t)q] * (uint64_t)r.im;
+      p.ncols = (uint64_t)(j_lo[(size_t)q + 1] - j_lo[(size_t)q]) * (uint64_t)r.im;
     }
-    fa.pl_feature = 1;
-    fa.nfield = 27;
-    fa.im = r.im; fa.jm = r.jm; fa.km = r.km;
-    fa.k1 = k1 - 1; fa.k2 = k2 - 1;
-    fa.missing = r.missing;
-    tree_range(b, 0, &fa.tree_begin, &fa.tree_end);
-    fa.apply_pow10 = 1;
-    fa.scale = r.ohscale;
-    fa.out = oh_ml;
-    fa.flags = b.d_flags.p;
-    if (pick_kernel(b) == KernelKind::Wide) ensure_wide(b);
-    const uint64_t slab_rows = plane * (uint64_t)(k2 - k1 + 1);
-    LaunchTuning tune = b.tune;
-    leaf_room(b, slab_rows, fa.tree_end - fa.tree_begin, tune, r.im, r.jm, 0);
-    const bool deferring = defer_prepare(b, slab_rows, tune, stream);
-    HIP_CHECK(launch_predict_fields(pick_kernel(b), device_forest(b), fa, b.dev.num_cus, stream, tune));
-    if (deferring) defer_look(b, slab_rows, stream);
-  }
+    HIP_CHECK(launch_feature_prep(p, aod, s));
+  };
   PostArgs po;
   po.im = r.im; po.jm = r.jm; po.km = r.km;
   po.avogad = r.avogad; po.runiv = r.runiv; po.epsilon = r.epsilon;
   po.ple_mod = r.ple_mod; po.t_mod = r.t_mod; po.q_mod = r.q_mod; po.tropp = r.tropp_mod;
   po.default_oh = r.default_oh; po.oh_ml = oh_ml; po.oh = r.oh; po.ndwet = r.ndwet;
-  HIP_CHECK(launch_post_process(po, stream));
+  auto post_piece = [&](int q, hipStream_t s) {
+    PostArgs p = po;
+    if (npieces > 1) {
+      p.col0 = (uint64_t)j_lo[(size_t)q] * (uint64_t)r.im;
+      p.ncols = (uint64_t)(j_lo[(size_t)q + 1] - j_lo[(size_t)q]) * (uint64_t)r.im;
+    }
+    HIP_CHECK(launch_post_process(p, s));
+  };
+
+  prep_piece(0, stream);
+  if (npieces > 1) {
+    prep_piece(1, side);
+    HIP_CHECK(hipEventRecord(b.run1_prep[1], side));
+  }
+  // the one wait in the middle of a tick: the slab count sizes the walk's launches (and the reference asserts on it,
+  // :287-288); it was enqueued before everything else of this tick and the features are being computed meanwhile
+  HIP_CHECK(hipEventSynchronize(b.run1_slab));
+  const int32_t slab[2] = {b.h_slab.p[0], b.h_slab.p[1]};
+  if (!r.dynamic_k_range && slab[1] != 0) {
+    (void)hipStreamSynchronize(side);
+    (void)hipStreamSynchronize(stream);
+    throw OhxError("OH Prediction: Minimum tropopause pressure is not low enough!");
+  }
+  const int k1 = r.km - slab[0] + 1, k2 = r.km;   // 1-based (:300-301)
+  if (r.k1) *r.k1 = k1;
+  if (r.k2) *r.k2 = k2;
+
+  const float* fields[27] = {r.lat_deg, pl_bst, r.t_bst, r.no2, r.o3, r.ch4, r.co, r.isop, r.acet, r.c2h6, r.c3h8,
+                             r.prpe, r.alk4, r.mp, r.h2o2, tauclwdn, tauclidn, taucliup, tauclwup, r.cloud, r.qv,
+                             strato3, r.albuv, aodup, aoddn, r.ch2o, r.sza};      // order of :313-339
+  static const int32_t is2d[27] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};
+  if (kind == KernelKind::Wide) ensure_wide(b);
+  // OH_ML := 0 (side stream) lies before the first store of a walk
+  HIP_CHECK(hipEventRecord(b.run1_join, side));
+  HIP_CHECK(hipStreamWaitEvent(stream, b.run1_join, 0));
+  for (int q = 0; q < npieces; ++q) {
+    const int jq = j_lo[(size_t)q + 1] - j_lo[(size_t)q];
+    const uint64_t first = (uint64_t)j_lo[(size_t)q] * (uint64_t)r.im;        // the piece's first column
+    if (q >= 1) HIP_CHECK(hipStreamWaitEvent(stream, b.run1_prep[(size_t)q], 0));      // its features are there
+    if (k2 >= k1 && jq > 0) {
+      FieldsArgs fa{};
+      fa.is2d_mask = 0;
+      for (int f = 0; f < 27; ++f) {
+        fa.field[f] = fields[f] + first;
+        if (is2d[f]) fa.is2d_mask |= (1u << f);
+      }
+      fa.pl_feature = 1;
+      fa.nfield = 27;
+      fa.im = r.im; fa.jm = jq; fa.km = r.km;
+      fa.level_stride = npieces > 1 ? plane : 0;
+      fa.k1 = k1 - 1; fa.k2 = k2 - 1;
+      fa.missing = r.missing;
+      tree_range(b, 0, &fa.tree_begin, &fa.tree_end);
+      fa.apply_pow10 = 1;
+      fa.scale = r.ohscale;
+      fa.out = oh_ml + first;
+      fa.flags = b.d_flags.p;
+      const uint64_t slab_rows = (uint64_t)r.im * (uint64_t)jq * (uint64_t)(k2 - k1 + 1);
+      LaunchTuning tune = b.tune;
+      leaf_room(b, slab_rows, fa.tree_end - fa.tree_begin, tune, r.im, jq, 0);
+      const bool deferring = defer_prepare(b, slab_rows, tune, stream);
+      HIP_CHECK(launch_predict_fields(kind, device_forest(b), fa, b.dev.num_cus, stream, tune));
+      if (deferring && q + 1 == npieces) defer_look(b, slab_rows, stream);
+    }
+    if (npieces == 1) {
+      post_piece(0, stream);
+      break;
+    }
+    // the piece is walked: its mask and unit conversion, then the features of the piece after next, beside the next walk
+    HIP_CHECK(hipEventRecord(b.run1_walk[(size_t)q], stream));
+    HIP_CHECK(hipStreamWaitEvent(side, b.run1_walk[(size_t)q], 0));
+    post_piece(q, side);
+    if (q + 2 < npieces) {
+      prep_piece(q + 2, side);
+      HIP_CHECK(hipEventRecord(b.run1_prep[(size_t)q + 2], side));
+    }
+  }
+  if (npieces > 1) {       // the caller's stream ends behind everything the side stream did
+    HIP_CHECK(hipEventRecord(b.run1_join, side));
+    HIP_CHECK(hipStreamWaitEvent(stream, b.run1_join, 0));
+  }
 }
 
 int OHXBoosterRun1Device(BoosterHandle handle, const OHXRun1Args* args, void* stream) {

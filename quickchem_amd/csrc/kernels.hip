@@ -208,14 +208,27 @@ __device__ __forceinline__ bool fill_tile_fields_burst(const FieldsArgs& a, floa
   return lane_nan;
 }
 
+// Where slab row m = i + im * (j + jm * k') sits in the 3-D arrays, counted from the slab's first level, and in the 2-D
+// ones: m itself and m % (im * jm) - unless the (im, jm) at hand is a range of j of a wider grid (FieldsArgs::level_stride)
+struct CellAt {
+  uint64_t at3, at2;
+};
+__device__ __forceinline__ CellAt cell_at(const FieldsArgs& a, uint64_t plane, uint64_t m) {
+  const uint64_t k = m / plane, col = m - k * plane;
+  return CellAt{a.level_stride ? k * a.level_stride + col : m, col};
+}
+__device__ __forceinline__ uint64_t level_floats(const FieldsArgs& a, uint64_t plane) {
+  return a.level_stride ? a.level_stride : plane;
+}
+
 // what the fused path stores for a gridcell: the margin (optional) and 10**margin * OHscale (:369, :1569)
 __device__ __forceinline__ void store_oh(const FieldsArgs& a, float* __restrict__ out, float* __restrict__ margin_out,
-                                         uint64_t slab_out, uint64_t m, float acc) {
+                                         uint64_t slab_out, uint64_t m, uint64_t at3, float acc) {
   if (margin_out) margin_out[m] = acc;
   float oh = acc;
   if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);      // 10.0**x rounded once from double: agrees with a correctly rounded powf
   oh = oh * a.scale;
-  out[slab_out + m] = oh;
+  out[slab_out + at3] = oh;
 }
 
 // The OH shape (27 columns, 27 features): a row held in registers, so the NEXT tile's rows can
@@ -1228,8 +1241,8 @@ __global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4)))
   const bool missing_is_nan = a.missing != a.missing;
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
   const uint64_t nrow = plane * (uint64_t)(a.k2 - a.k1 + 1);
-  const uint64_t slab = plane * (uint64_t)(a.k1 - a.src_k0);
-  const uint64_t slab_out = plane * (uint64_t)(a.k1 - a.out_k0);
+  const uint64_t slab = level_floats(a, plane) * (uint64_t)(a.k1 - a.src_k0);
+  const uint64_t slab_out = level_floats(a, plane) * (uint64_t)(a.k1 - a.out_k0);
   uint32_t block = blockIdx.x;
   if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const uint64_t wave_id = (uint64_t)block * kRingWaves + wave;
@@ -1245,7 +1258,8 @@ __global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4)))
     uint64_t m = 0;
     if (tile_id < a.tile_end) m = tile_row(a.shape, tile_id, lane, nrow, &valid);
     const bool live = __any(valid);
-    const bool lane_nan = live && fill_tile_fields(a, tile, 27u, m, valid ? m % plane : 0, slab, valid, missing_is_nan);
+    const CellAt at = cell_at(a, plane, valid ? m : 0);
+    const bool lane_nan = live && fill_tile_fields(a, tile, 27u, at.at3, at.at2, slab, valid, missing_is_nan);
     bool wave_nan = __any(lane_nan);
     bool keep = valid;
     if (wave_nan && a.defer_count != nullptr && a.defer_cap == 0u) {
@@ -1267,7 +1281,7 @@ __global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4)))
       }
     }
     const float acc = ring_walk_tile(rg, fr.base_score, tile, live, wave_nan, lane, wave);
-    if (keep && !rg.gave_up) store_oh(a, out, margin_out, slab_out, m, acc);
+    if (keep && !rg.gave_up) store_oh(a, out, margin_out, slab_out, m, at.at3, acc);
   }
   if (rg.gave_up && a.flags) atomicOr(a.flags, kFlagRingTimeout);
 }
@@ -1351,8 +1365,8 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
   const bool missing_is_nan = a.missing != a.missing;
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
   const uint64_t nrow = plane * (uint64_t)(a.k2 - a.k1 + 1);
-  const uint64_t slab = plane * (uint64_t)(a.k1 - a.src_k0);
-  const uint64_t slab_out = plane * (uint64_t)(a.k1 - a.out_k0);
+  const uint64_t slab = level_floats(a, plane) * (uint64_t)(a.k1 - a.src_k0);
+  const uint64_t slab_out = level_floats(a, plane) * (uint64_t)(a.k1 - a.out_k0);
   // as in the rows kernel: blocks b and b + 8 share an XCD, give every XCD one contiguous run of tiles
   uint32_t block = blockIdx.x;
   if (a.xcd_remap && (gridDim.x & 7u) == 0u) block = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -1372,7 +1386,8 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
         bool valid;
         const uint64_t m = tile_row(a.shape, tile_id, lane, nrow, &valid);
         if (!__any(valid) || t0 >= t1) continue;
-        const bool lane_nan = fill_tile_fields_burst(a, tile, fr.num_feature, m, valid ? m % plane : 0, slab, valid, missing_is_nan);
+        const CellAt at = cell_at(a, plane, valid ? m : 0);
+        const bool lane_nan = fill_tile_fields_burst(a, tile, fr.num_feature, at.at3, at.at2, slab, valid, missing_is_nan);
         float* leaves = a.leaf_buf + ((size_t)(tile_id - a.tile_begin) * ntree - a.tree_begin) * kWave + lane;
         (void)walk_tile<FMT, CHAINS, TOPS>(fr, heads, t0, t1, tile, __any(lane_nan), first, nfirst, leaves);
       }
@@ -1400,7 +1415,8 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
       m = tile_row(a.shape, tile_id, lane, nrow, &valid);
     }
     if (!__any(valid)) continue;                       // a brick without a row of the slab, a tile of empty slots
-    const bool lane_nan = fill_tile_fields(a, tile, fr.num_feature, m, valid ? m % plane : 0, slab, valid, missing_is_nan);
+    const CellAt at = cell_at(a, plane, valid ? m : 0);
+    const bool lane_nan = fill_tile_fields(a, tile, fr.num_feature, at.at3, at.at2, slab, valid, missing_is_nan);
     bool wave_nan = __any(lane_nan);
     bool keep = valid;
     // rows with missing values leave for the second launch, as in the rows kernel (every lane filled its own row here)
@@ -1423,7 +1439,7 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
       }
     }
     const float acc = walk_tile<FMT, CHAINS, TOPS>(fr, heads, a.tree_begin, a.tree_end, tile, wave_nan, first, nfirst);
-    if (keep) store_oh(a, out, margin_out, slab_out, m, acc);
+    if (keep) store_oh(a, out, margin_out, slab_out, m, at.at3, acc);
   }
 }
 
@@ -1433,7 +1449,7 @@ __global__ __launch_bounds__(kBlock) void combine_leaves_fields_kernel(FieldsArg
   const int lane = threadIdx.x & (kWave - 1);
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
   const uint64_t nrow = plane * (uint64_t)(a.k2 - a.k1 + 1);
-  const uint64_t slab_out = plane * (uint64_t)(a.k1 - a.out_k0);
+  const uint64_t slab_out = level_floats(a, plane) * (uint64_t)(a.k1 - a.out_k0);
   const uint64_t ntiles = a.tile_end - a.tile_begin, nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
   const uint32_t ntree = a.tree_end - a.tree_begin;
   for (uint64_t w = (uint64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave; w < ntiles; w += nwaves) {
@@ -1444,7 +1460,7 @@ __global__ __launch_bounds__(kBlock) void combine_leaves_fields_kernel(FieldsArg
     float acc = base_score;
 #pragma unroll 4
     for (uint32_t t = 0; t < ntree; ++t) acc += leaves[(size_t)t * kWave];
-    if (valid) store_oh(a, out, margin_out, slab_out, m, acc);
+    if (valid) store_oh(a, out, margin_out, slab_out, m, cell_at(a, plane, m).at3, acc);
   }
 }
 
@@ -1649,10 +1665,13 @@ __global__ __launch_bounds__(kBlock) void cluster_keys_kernel(DeviceForest fr, C
 // (OH_GridCompMod.F90:1468-1478); a suffix scan from the bottom would round differently.
 __global__ __launch_bounds__(kBlock) void feature_pointwise_kernel(PrepArgs a, float* __restrict__ aod) {
 #pragma clang fp contract(off)
+  // blockIdx.y = level; the block's threads stride over the columns col0 .. col0 + ncols - 1
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
-  const uint64_t total = plane * (uint64_t)a.km;
+  const uint64_t ncols = a.ncols ? a.ncols : plane;
+  const uint64_t level = plane * (uint64_t)blockIdx.y;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += stride) {
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += stride) {
+    const uint64_t col = a.col0 + c, m = level + col;
     a.pl_bst[m] = (a.ple_bst[m] + a.ple_bst[m + plane]) * 0.5f;               // :1488
     const float thick = a.zle_bst[m] - a.zle_bst[m + plane];                  // ZLE(k-1) - ZLE(k), :1451
     float sc = a.sca[0][m] + a.sca[1][m];                                      // BC+OC+BR+DU+SU+SS+NI, :1456-1457
@@ -1662,7 +1681,7 @@ __global__ __launch_bounds__(kBlock) void feature_pointwise_kernel(PrepArgs a, f
     sc = sc + a.sca[5][m];
     sc = sc + a.sca[6][m];
     aod[m] = thick * sc;
-    if (m < plane) a.strato3[m] = a.gmito3[m] - a.gmitto3[m];                  // :1446
+    if (blockIdx.y == 0) a.strato3[col] = a.gmito3[col] - a.gmitto3[col];      // :1446
   }
 }
 
@@ -1673,9 +1692,10 @@ __global__ __launch_bounds__(kBlock) void feature_column_sums_kernel(PrepArgs a,
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t ncols = a.ncols ? a.ncols : plane;
   const uint64_t col = ((uint64_t)blockIdx.x * kWavesPerBlock + wave) * kWave + lane;
-  const bool valid = col < plane;
-  const uint64_t c = valid ? col : plane - 1;
+  const bool valid = col < ncols;
+  const uint64_t c = a.col0 + (valid ? col : ncols - 1);
   const float* src = blockIdx.y == 0 ? a.tauclw : (blockIdx.y == 1 ? a.taucli : aod);
   float* up = blockIdx.y == 0 ? a.tauclwup : (blockIdx.y == 1 ? a.taucliup : a.aodup);
   float* dn = blockIdx.y == 0 ? a.tauclwdn : (blockIdx.y == 1 ? a.tauclidn : a.aoddn);
@@ -1702,8 +1722,10 @@ template <int KM>
 __global__ __launch_bounds__(kBlock) void feature_column_sums_reg_kernel(PrepArgs a, const float* __restrict__ aod) {
 #pragma clang fp contract(off)
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
-  const uint64_t col = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (col >= plane) return;
+  const uint64_t ncols = a.ncols ? a.ncols : plane;
+  uint64_t col = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (col >= ncols) return;
+  col += a.col0;
   const float* src = (blockIdx.y == 0 ? a.tauclw : (blockIdx.y == 1 ? a.taucli : aod)) + col;
   float* up = (blockIdx.y == 0 ? a.tauclwup : (blockIdx.y == 1 ? a.taucliup : a.aodup)) + col;
   float* dn = (blockIdx.y == 0 ? a.tauclwdn : (blockIdx.y == 1 ? a.tauclidn : a.aoddn)) + col;
@@ -1762,11 +1784,13 @@ __global__ __launch_bounds__(kBlock) void k_slab_kernel(SlabArgs a) {
 // tropopause mask and mol/mol -> molec/cm3 (:1247-1257, 1579-1595)
 __global__ __launch_bounds__(kBlock) void post_process_kernel(PostArgs a) {
 #pragma clang fp contract(off)
+  // blockIdx.y = level; the block's threads stride over the columns col0 .. col0 + ncols - 1
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
-  const uint64_t total = plane * (uint64_t)a.km;
+  const uint64_t ncols = a.ncols ? a.ncols : plane;
+  const uint64_t level = plane * (uint64_t)blockIdx.y;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += stride) {
-    const uint64_t col = m % plane;
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += stride) {
+    const uint64_t col = a.col0 + c, m = level + col;
     const float pl = (a.ple_mod[m] + a.ple_mod[m + plane]) * 0.5f;
     const float q = a.q_mod[m];
     const float tv = a.t_mod[m] * (1.0f + q / a.epsilon) / (1.0f + q);
@@ -2427,13 +2451,22 @@ hipError_t launch_cluster_keys(const DeviceForest& fr, const ClusterArgs& a, int
   }
 }
 
+// grid of the kernels that take a level per blockIdx.y and stride over a range of columns
+static dim3 level_grid(uint64_t ncols, int km) {
+  uint64_t bx = (ncols + (uint64_t)kBlock * 4 - 1) / ((uint64_t)kBlock * 4);     // four columns per thread
+  if (bx < 1) bx = 1;
+  if (bx > 1024) bx = 1024;
+  return dim3((unsigned)bx, (unsigned)km);
+}
+
 hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_t stream) {
   const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
   if (plane == 0 || a.km <= 0) return hipSuccess;
-  hipLaunchKernelGGL(feature_pointwise_kernel, dim3(grid_for(plane * (uint64_t)a.km, 256, 16)), dim3(kBlock), 0, stream,
-                     a, aod_scratch);
+  if (a.col0 + a.ncols > plane || a.km > 65535) return hipErrorInvalidValue;
+  const uint64_t ncols = a.ncols ? a.ncols : plane;
+  hipLaunchKernelGGL(feature_pointwise_kernel, level_grid(ncols, a.km), dim3(kBlock), 0, stream, a, aod_scratch);
   if (a.km == 72) {        // GEOS's 72 levels: the column in registers
-    hipLaunchKernelGGL(feature_column_sums_reg_kernel<72>, dim3((unsigned)((plane + kBlock - 1) / kBlock), 3), dim3(kBlock), 0,
+    hipLaunchKernelGGL(feature_column_sums_reg_kernel<72>, dim3((unsigned)((ncols + kBlock - 1) / kBlock), 3), dim3(kBlock), 0,
                        stream, a, (const float*)aod_scratch);
     return hipGetLastError();
   }
@@ -2442,7 +2475,7 @@ hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_
   hipError_t e = ensure_lds(feature_column_sums_kernel, lds);
   if (e != hipSuccess) return e;
   const uint64_t cols_per_block = (uint64_t)kWavesPerBlock * kWave;
-  hipLaunchKernelGGL(feature_column_sums_kernel, dim3((unsigned)((plane + cols_per_block - 1) / cols_per_block), 3),
+  hipLaunchKernelGGL(feature_column_sums_kernel, dim3((unsigned)((ncols + cols_per_block - 1) / cols_per_block), 3),
                      dim3(kBlock), lds, stream, a, (const float*)aod_scratch);
   return hipGetLastError();
 }
@@ -2462,9 +2495,10 @@ hipError_t launch_k_slab(const SlabArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_post_process(const PostArgs& a, hipStream_t stream) {
-  const uint64_t total = (uint64_t)a.im * (uint64_t)a.jm * (uint64_t)a.km;
-  if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(post_process_kernel, dim3(grid_for(total, 256, 16)), dim3(kBlock), 0, stream, a);
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  if (plane == 0 || a.km <= 0) return hipSuccess;
+  if (a.col0 + a.ncols > plane || a.km > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(post_process_kernel, level_grid(a.ncols ? a.ncols : plane, a.km), dim3(kBlock), 0, stream, a);
   return hipGetLastError();
 }
 

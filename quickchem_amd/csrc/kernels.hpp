@@ -177,6 +177,9 @@ struct LaunchTuning {
   // ring kernels: tiles per wave and launch (0 = one launch for the whole batch).  C360 step 24.28 ms at 16, 24.13 at 64,
   // 24.07 in one launch; the fused fields kernel 26.85 / 26.65 / 27.05 (profiles/r04_sweeps.txt)
   int ring_rounds = 64;
+  // OH Run1 on a big slab: ranges of j walked one after the other, the next one's feature engineering and the last
+  // one's post-processing beside the walk (capi.cpp run1_device): 0 = as many as pay, 1 = one piece, n = n pieces
+  int run1_pieces = 0;
   // ring kernels: CUs left free (a ring block owns its CU - all of its vector registers and LDS - for the length of a
   // launch, so a collective's kernels enqueued beside it only get on the chip at a launch boundary; 0 = take them all)
   int reserve_cus = 0;
@@ -215,6 +218,11 @@ struct FieldsArgs {
   uint32_t pl_feature = 1;     // feature index that is divided by 100 (Pa -> hPa), 0xFFFFFFFF for none
   uint32_t nfield = 0;
   int im = 0, jm = 0, km = 0, k1 = 0, k2 = 0;  // k1..k2 inclusive, 0-based
+  // floats between a gridcell and the one above it in the 3-D arrays; 0 = im * jm.  Not 0: the (im, jm) given here is
+  // a range of j of a wider grid - OH Run1 walks a big slab in such pieces so that the feature engineering of the next
+  // and the post-processing of the last run beside the walk (capi.cpp run1_device) - and every field pointer (2-D ones
+  // too) and `out` point at the piece's first column
+  uint64_t level_stride = 0;
   int src_k0 = 0;              // level the 3-D source arrays start at (0 = whole arrays, k1 = slab-only copies)
   int out_k0 = 0;              // same for `out`
   float missing = 0.0f;
@@ -243,6 +251,7 @@ struct FieldsArgs {
 // OH Run1's feature engineering and post-processing (include/ohxgb.h part 3), device pointers.
 struct PrepArgs {
   int im = 0, jm = 0, km = 0;
+  uint64_t col0 = 0, ncols = 0;      // columns [col0, col0 + ncols) of the im * jm only (ncols 0 = all): Run1's pieces
   const float *ple_bst = nullptr, *zle_bst = nullptr, *tauclw = nullptr, *taucli = nullptr;
   const float* sca[7] = {};
   const float *gmito3 = nullptr, *gmitto3 = nullptr;
@@ -260,6 +269,7 @@ struct SlabArgs {
 
 struct PostArgs {
   int im = 0, jm = 0, km = 0;
+  uint64_t col0 = 0, ncols = 0;      // as PrepArgs
   float avogad = 0, runiv = 0, epsilon = 0;
   const float *ple_mod = nullptr, *t_mod = nullptr, *q_mod = nullptr, *tropp = nullptr;
   const float *default_oh = nullptr, *oh_ml = nullptr;

@@ -65,6 +65,45 @@ def test_run1_gpu_vs_oracle(deep_model, dynamic, grid):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("grid,pieces,dynamic", [((37, 11, 72), 2, True), ((24, 30, 137), 3, False), ((40, 53, 72), 5, True),
+                                                 ((144, 200, 72), 3, True), ((144, 200, 72), 4, False)])
+def test_run1_in_pieces_is_run1(deep_model, grid, pieces, dynamic):
+    """(r5) OH Run1 walks a big slab in ranges of j - the next range's feature engineering and the last one's mask and
+    unit conversion on a second stream beside the walk (capi.cpp run1_device; a C360 slab by itself, here forced by
+    ohx_run1_pieces on grids whose j extent is no multiple of the brick's four, small enough for the trees-split-over-
+    waves form and big enough for the ring kernel): every output, the DIAG dumps included, is what one piece gives, bit for
+    bit - and that is checked against the oracle; with -999.0 and NaN among the inputs (the rows that hold them go
+    through each piece's own second launch)."""
+    st = helpers.run1_state(grid, seed=grid[1])
+    rng = np.random.default_rng(3)
+    for name in ("no2", "cloud", "ch2o"):
+        a = st[name] = st[name].copy()
+        mask = rng.random(a.shape) < 3e-4
+        a[mask] = np.where(rng.random(int(mask.sum())) < 0.5, np.float32(-999.0), np.float32(np.nan))
+    want = oracle_run1(deep_model.image, st, dynamic_k_range=dynamic, want_diag=True)
+    outs = []
+    for n in (1, pieces):
+        b = capi.Booster(model_buffer=deep_model.image)
+        b.set_param("ohx_kernel", "ring")
+        b.set_param("ohx_run1_pieces", n)
+        outs.append(b.run1(st, dynamic_k_range=dynamic, want_diag=True))
+        b.free()
+    one, many = outs
+    assert (one["k1"], one["k2"]) == (many["k1"], many["k2"]) == (want["k1"], want["k2"])
+    for name in one:
+        if name in ("k1", "k2"):
+            continue
+        assert np.array_equal(helpers.bits(many[name]), helpers.bits(one[name])), name
+    assert np.array_equal(helpers.bits(many["ndwet"]), helpers.bits(want["ndwet"]))
+    k1 = many["k1"]
+    assert np.all(many["oh_boost"][:, :, :k1 - 1] == 0)
+    assert helpers.ulp_diff(many["oh_boost"][:, :, k1 - 1:], want["oh_boost"][:, :, k1 - 1:]).max() <= 2
+    assert helpers.ulp_diff(many["oh"], want["oh"]).max() <= 3
+    for name in ("diag_tauclwdn", "diag_taucliup", "diag_aodup", "diag_aoddn", "diag_aod", "diag_pl_bst", "diag_strato3"):
+        assert np.array_equal(helpers.bits(many[name]), helpers.bits(want[name])), name
+
+
+@pytest.mark.gpu
 def test_run1_gpu_engineered_features_bit_exact(small_model):
     """The engineered features themselves: run the prep on the GPU and read the margins of a
     booster whose every split is on an engineered feature - any bit of difference in a cumulative
