@@ -241,19 +241,27 @@ RowPool g_row_pool;
 struct HostRegistry {
   std::mutex mu;
   std::atomic<bool> on{false};
-  std::unordered_map<const void*, size_t> pinned;     // base -> bytes, registered by us
+  struct Pin {
+    size_t bytes;
+    void* mapped;      // where the GPU sees the array (hipHostGetDevicePointer, asked once)
+  };
+  std::unordered_map<const void*, Pin> pinned;        // base -> what we registered
   std::unordered_map<const void*, size_t> refused;    // base -> bytes the driver would not take
   size_t bytes = 0;
-  // true when [p, p + n) is registered afterwards
-  bool want(const void* p, size_t n) {
+  // true when [p, p + n) is registered afterwards; *mapped (optional) = the address the GPU reaches it at, or null
+  bool want(const void* p, size_t n, void** mapped = nullptr) {
+    if (mapped) *mapped = nullptr;
     if (!on.load(std::memory_order_relaxed) || p == nullptr || n == 0) return false;
     std::lock_guard<std::mutex> g(mu);
     auto it = pinned.find(p);
     if (it != pinned.end()) {
-      if (it->second >= n) return true;
+      if (it->second.bytes >= n) {
+        if (mapped) *mapped = it->second.mapped;
+        return true;
+      }
       (void)hipDeviceSynchronize();                       // no copy of the old range may still be in flight
       (void)hipHostUnregister(const_cast<void*>(p));      // the same array, grown: again from the start
-      bytes -= it->second;
+      bytes -= it->second.bytes;
       pinned.erase(it);
     }
     auto rf = refused.find(p);
@@ -263,8 +271,14 @@ struct HostRegistry {
       refused[p] = n;
       return false;
     }
-    pinned[p] = n;
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, const_cast<void*>(p), 0) != hipSuccess) {
+      (void)hipGetLastError();
+      dev = nullptr;
+    }
+    pinned[p] = Pin{n, dev};
     bytes += n;
+    if (mapped) *mapped = dev;
     return true;
   }
   void release_all() {
@@ -286,7 +300,7 @@ struct HostRegistry {
     if (it == pinned.end()) return false;
     (void)hipDeviceSynchronize();
     (void)hipHostUnregister(const_cast<void*>(p));
-    bytes -= it->second;
+    bytes -= it->second.bytes;
     pinned.erase(it);
     return true;
   }
@@ -297,6 +311,7 @@ HostRegistry g_host_registry;
 // copy_arrays_kernel (the GPU reads or writes the caller's memory over PCIe itself) as long as the whole list is
 // small - a rank-sized block, where forty separate copies cost forty fixed prices; big lists and arrays that are not
 // registered go through hipMemcpyAsync.
+std::atomic<uint32_t> g_copy_blocks{0};      // experiment knob "ohx_copy_blocks": blocks per array of copy_arrays_kernel (0 = up to 2048)
 struct HostMover {
   static constexpr size_t kKernelBytesMax = 64u << 20;
   CopyList list;
@@ -308,9 +323,8 @@ struct HostMover {
     if (count == 0) return;
     const void* host = to_device ? (const void*)src : (const void*)dst;
     void* mapped = nullptr;
-    if (g_host_registry.want(host, count * sizeof(float)) && list.count < kCopyListMax &&
-        list_bytes + count * sizeof(float) <= kKernelBytesMax &&
-        hipHostGetDevicePointer(&mapped, const_cast<void*>(host), 0) == hipSuccess && mapped != nullptr) {
+    if (g_host_registry.want(host, count * sizeof(float), &mapped) && mapped != nullptr && list.count < kCopyListMax &&
+        list_bytes + count * sizeof(float) <= kKernelBytesMax) {
       list.src[list.count] = to_device ? static_cast<const float*>(mapped) : src;
       list.dst[list.count] = to_device ? dst : static_cast<float*>(mapped);
       list.n[list.count] = count;
@@ -325,9 +339,8 @@ struct HostMover {
   void add_slice(float* dev, const float* host_base, size_t whole, size_t offset, size_t count) {
     if (count == 0) return;
     void* mapped = nullptr;
-    if (g_host_registry.want(host_base, whole * sizeof(float)) && list.count < kCopyListMax &&
-        list_bytes + count * sizeof(float) <= kKernelBytesMax &&
-        hipHostGetDevicePointer(&mapped, const_cast<float*>(host_base), 0) == hipSuccess && mapped != nullptr) {
+    if (g_host_registry.want(host_base, whole * sizeof(float), &mapped) && mapped != nullptr && list.count < kCopyListMax &&
+        list_bytes + count * sizeof(float) <= kKernelBytesMax) {
       float* m = static_cast<float*>(mapped) + offset;
       list.src[list.count] = to_device ? m : dev;
       list.dst[list.count] = to_device ? dev : m;
@@ -342,7 +355,7 @@ struct HostMover {
                              count * sizeof(float), to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream));
   }
   void go() {
-    HIP_CHECK(launch_copy_arrays(list, stream));
+    HIP_CHECK(launch_copy_arrays(list, stream, g_copy_blocks.load(std::memory_order_relaxed)));
     list.count = 0;
     list_bytes = 0;
   }
@@ -414,6 +427,7 @@ struct BoosterObj {
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : run1_prep) (void)hipEventDestroy(e);
     for (hipEvent_t e : run1_walk) (void)hipEventDestroy(e);
+    for (hipEvent_t e : run1_feed_events) (void)hipEventDestroy(e);
     if (train.side) (void)hipStreamDestroy(train.side);
     if (train.fork) (void)hipEventDestroy(train.fork);
     if (train.join) (void)hipEventDestroy(train.join);
@@ -462,7 +476,7 @@ struct BoosterObj {
   // side stream beside the caller's
   hipStream_t s_run1 = nullptr;
   hipEvent_t run1_fork = nullptr, run1_slab = nullptr, run1_join = nullptr;
-  std::vector<hipEvent_t> run1_prep, run1_walk;
+  std::vector<hipEvent_t> run1_prep, run1_walk, run1_feed_events;
   PinnedBuf<int32_t> h_slab;
   std::vector<DevBuf<float>> d_stage;  // fused host path: per-field staging
   DevBuf<float> d_stage_out, d_stage_margin;
@@ -1275,6 +1289,8 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     const int k = atoi(value);
     if (k < 0) throw OhxError("ohx_ring_rounds must be >= 0");
     b->tune.ring_rounds = k;
+  } else if (n == "ohx_copy_blocks") {
+    g_copy_blocks.store((uint32_t)std::max(0, atoi(value)));
   } else if (n == "ohx_run1_pieces") {
     const int k = atoi(value);
     if (k < 0 || k > 64) throw OhxError("ohx_run1_pieces must be 0 (auto) .. 64");
@@ -1516,7 +1532,18 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
   API_END();
 }
 
-static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream) {
+// The host form's side of a tick (OHXBoosterRun1): its arrays cross PCIe in three lists on a copy stream, and
+// run1_device says when - what the slab count needs first, what the feature engineering needs behind it, and the
+// rest once the slab is known (of the sixteen fields only the walk reads, the slab's levels alone).
+struct Run1Feed {
+  virtual ~Run1Feed() = default;
+  // each enqueues copies on the feed's own stream and returns an event recorded behind them
+  virtual hipEvent_t slab_inputs() = 0;                              // PLE and TROPP of the model
+  virtual hipEvent_t prep_inputs() = 0;                              // what the feature engineering reads
+  virtual void rest(int k1, int k2, hipEvent_t* walk_inputs, hipEvent_t* post_inputs) = 0;      // 1-based slab levels
+};
+
+static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream, Run1Feed* feed = nullptr) {
   if (r.im <= 0 || r.jm <= 0 || r.km <= 0) throw OhxError("OHXBoosterRun1: im, jm, km must be positive");
   if (b.forest.num_feature != 27) throw OhxError("OHXBoosterRun1 needs the 27-feature OH booster");
   const void* need[] = {r.ple_mod, r.t_mod, r.q_mod, r.tropp_mod, r.ple_bst, r.zle_bst, r.tauclw, r.taucli,
@@ -1561,6 +1588,10 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   hipStream_t side = b.s_run1;
   HIP_CHECK(hipEventRecord(b.run1_fork, stream));            // the side stream starts behind what the caller has enqueued
   HIP_CHECK(hipStreamWaitEvent(side, b.run1_fork, 0));
+  // host form: PLE and TROPP cross first, and the slab count is enqueued behind them before anything else is even
+  // listed - its answer is back on the host while the features' inputs are still crossing, so the walk's own inputs
+  // follow them over PCIe without a gap
+  if (feed != nullptr) HIP_CHECK(hipStreamWaitEvent(side, feed->slab_inputs(), 0));
 
   SlabArgs sa;
   sa.im = r.im; sa.jm = r.jm; sa.km = r.km;
@@ -1571,6 +1602,11 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   HIP_CHECK(hipMemcpyAsync(b.h_slab.p, b.d_slab.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, side));
   HIP_CHECK(hipEventRecord(b.run1_slab, side));
   HIP_CHECK(hipMemsetAsync(oh_ml, 0, vol * sizeof(float), side));            // self%OH_ML(:,:,:) = 0.0 (:1559)
+  hipEvent_t prep_inputs = nullptr;
+  if (feed != nullptr) {
+    prep_inputs = feed->prep_inputs();
+    HIP_CHECK(hipStreamWaitEvent(stream, prep_inputs, 0));
+  }
 
   // pieces: as many as the slab's tiles make whole launches of the ring kernel (at its most, all km levels), of whole
   // rows of bricks (four j); the pieces' extents do not depend on the slab count, which is not known yet
@@ -1579,7 +1615,11 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   if (kind == KernelKind::Ring && b.tune.run1_pieces != 1) {
     const uint64_t per_launch = (uint64_t)b.dev.num_cus * 16u * (uint64_t)std::max(1, b.tune.ring_rounds) * 64u;   // rows
     const uint64_t most = (uint64_t)vol;
-    npieces = b.tune.run1_pieces > 1 ? b.tune.run1_pieces : (int)std::min<uint64_t>(8, most / per_launch);
+    // measured (profiles/r05_sweeps.txt): more than one piece is slower - predict_fields_ring_kernel takes all of a CU's
+    // vector registers (4 x 128 of 512 per SIMD), so a streaming kernel enqueued beside it waits for its end, and the
+    // pieces' own launch tails cost 0.3 ms per C360 tick.  One piece unless asked for.
+    (void)most; (void)per_launch;
+    npieces = b.tune.run1_pieces > 1 ? b.tune.run1_pieces : 1;
     npieces = std::max(1, std::min(npieces, r.jm / 8));
   }
   std::vector<int> j_lo((size_t)npieces + 1, 0);
@@ -1623,6 +1663,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
 
   prep_piece(0, stream);
   if (npieces > 1) {
+    if (prep_inputs != nullptr) HIP_CHECK(hipStreamWaitEvent(side, prep_inputs, 0));      // later pieces' features run here
     prep_piece(1, side);
     HIP_CHECK(hipEventRecord(b.run1_prep[1], side));
   }
@@ -1638,6 +1679,12 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
   const int k1 = r.km - slab[0] + 1, k2 = r.km;   // 1-based (:300-301)
   if (r.k1) *r.k1 = k1;
   if (r.k2) *r.k2 = k2;
+  hipEvent_t post_inputs = nullptr;
+  if (feed != nullptr) {
+    hipEvent_t walk_inputs = nullptr;
+    feed->rest(k1, k2, &walk_inputs, &post_inputs);
+    HIP_CHECK(hipStreamWaitEvent(stream, walk_inputs, 0));
+  }
 
   const float* fields[27] = {r.lat_deg, pl_bst, r.t_bst, r.no2, r.o3, r.ch4, r.co, r.isop, r.acet, r.c2h6, r.c3h8,
                              r.prpe, r.alk4, r.mp, r.h2o2, tauclwdn, tauclidn, taucliup, tauclwup, r.cloud, r.qv,
@@ -1677,12 +1724,14 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream)
       if (deferring && q + 1 == npieces) defer_look(b, slab_rows, stream);
     }
     if (npieces == 1) {
+      if (post_inputs != nullptr) HIP_CHECK(hipStreamWaitEvent(stream, post_inputs, 0));
       post_piece(0, stream);
       break;
     }
     // the piece is walked: its mask and unit conversion, then the features of the piece after next, beside the next walk
     HIP_CHECK(hipEventRecord(b.run1_walk[(size_t)q], stream));
     HIP_CHECK(hipStreamWaitEvent(side, b.run1_walk[(size_t)q], 0));
+    if (post_inputs != nullptr) HIP_CHECK(hipStreamWaitEvent(side, post_inputs, 0));
     post_piece(q, side);
     if (q + 2 < npieces) {
       prep_piece(q + 2, side);
@@ -1843,29 +1892,106 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   if (h.im <= 0 || h.jm <= 0 || h.km <= 0) throw OhxError("OHXBoosterRun1: im, jm, km must be positive");
   const size_t plane = (size_t)h.im * (size_t)h.jm, vol = plane * (size_t)h.km, edge = plane * (size_t)(h.km + 1);
   OHXRun1Args d = h;
-  // every input goes to HBM once; 43 slots: 41 inputs + OH + NDWET (OH_boost reuses the scratch OH_ML)
-  struct In { const float* host; const float** dev; size_t n; };
+  // Every input goes to HBM once, in the order the tick needs it (Run1Feed): stage 0 = what the slab count reads,
+  // 1 = what the feature engineering reads, 3 = what only the walk reads - sixteen 3-D fields, of which the slab's
+  // levels cross, once the slab is known, and three 2-D ones - 2 = what the last kernel of the tick reads (the model's
+  // own T, Q and the default OH, on every level), which crosses last, under the walk (a 48 x 24 x 72 block: 51 of 72 levels, 1.5 of 10.3 MB less over PCIe).  An array that
+  // is passed twice (ONLINE_INST: T is both the model's and Boost's, OH_GridCompMod.F90:1326-1349) crosses once.
+  struct In { const float* host; const float** dev; size_t n; int stage; };
   In ins[] = {
-      {h.ple_mod, &d.ple_mod, edge}, {h.t_mod, &d.t_mod, vol}, {h.q_mod, &d.q_mod, vol}, {h.tropp_mod, &d.tropp_mod, plane},
-      {h.ple_bst, &d.ple_bst, edge}, {h.zle_bst, &d.zle_bst, edge}, {h.tauclw, &d.tauclw, vol}, {h.taucli, &d.taucli, vol},
-      {h.scacoef[0], &d.scacoef[0], vol}, {h.scacoef[1], &d.scacoef[1], vol}, {h.scacoef[2], &d.scacoef[2], vol},
-      {h.scacoef[3], &d.scacoef[3], vol}, {h.scacoef[4], &d.scacoef[4], vol}, {h.scacoef[5], &d.scacoef[5], vol},
-      {h.scacoef[6], &d.scacoef[6], vol}, {h.gmito3, &d.gmito3, plane}, {h.gmitto3, &d.gmitto3, plane},
-      {h.lat_deg, &d.lat_deg, plane}, {h.t_bst, &d.t_bst, vol}, {h.no2, &d.no2, vol}, {h.o3, &d.o3, vol},
-      {h.ch4, &d.ch4, vol}, {h.co, &d.co, vol}, {h.isop, &d.isop, vol}, {h.acet, &d.acet, vol}, {h.c2h6, &d.c2h6, vol},
-      {h.c3h8, &d.c3h8, vol}, {h.prpe, &d.prpe, vol}, {h.alk4, &d.alk4, vol}, {h.mp, &d.mp, vol}, {h.h2o2, &d.h2o2, vol},
-      {h.cloud, &d.cloud, vol}, {h.qv, &d.qv, vol}, {h.albuv, &d.albuv, plane}, {h.ch2o, &d.ch2o, vol},
-      {h.sza, &d.sza, plane}, {h.default_oh, &d.default_oh, vol}};
-  const size_t nin = sizeof(ins) / sizeof(ins[0]);
+      {h.ple_mod, &d.ple_mod, edge, 0}, {h.tropp_mod, &d.tropp_mod, plane, 0},
+      {h.ple_bst, &d.ple_bst, edge, 1}, {h.zle_bst, &d.zle_bst, edge, 1}, {h.tauclw, &d.tauclw, vol, 1}, {h.taucli, &d.taucli, vol, 1},
+      {h.scacoef[0], &d.scacoef[0], vol, 1}, {h.scacoef[1], &d.scacoef[1], vol, 1}, {h.scacoef[2], &d.scacoef[2], vol, 1},
+      {h.scacoef[3], &d.scacoef[3], vol, 1}, {h.scacoef[4], &d.scacoef[4], vol, 1}, {h.scacoef[5], &d.scacoef[5], vol, 1},
+      {h.scacoef[6], &d.scacoef[6], vol, 1}, {h.gmito3, &d.gmito3, plane, 1}, {h.gmitto3, &d.gmitto3, plane, 1},
+      {h.t_mod, &d.t_mod, vol, 2}, {h.q_mod, &d.q_mod, vol, 2}, {h.default_oh, &d.default_oh, vol, 2},
+      {h.lat_deg, &d.lat_deg, plane, 3}, {h.albuv, &d.albuv, plane, 3}, {h.sza, &d.sza, plane, 3},
+      {h.t_bst, &d.t_bst, vol, 3}, {h.no2, &d.no2, vol, 3}, {h.o3, &d.o3, vol, 3}, {h.ch4, &d.ch4, vol, 3}, {h.co, &d.co, vol, 3},
+      {h.isop, &d.isop, vol, 3}, {h.acet, &d.acet, vol, 3}, {h.c2h6, &d.c2h6, vol, 3}, {h.c3h8, &d.c3h8, vol, 3},
+      {h.prpe, &d.prpe, vol, 3}, {h.alk4, &d.alk4, vol, 3}, {h.mp, &d.mp, vol, 3}, {h.h2o2, &d.h2o2, vol, 3},
+      {h.cloud, &d.cloud, vol, 3}, {h.qv, &d.qv, vol, 3}, {h.ch2o, &d.ch2o, vol, 3}};
+  constexpr size_t nin = sizeof(ins) / sizeof(ins[0]);
   if (b->d_run1_stage.size() < nin + 3 + 9) b->d_run1_stage.resize(nin + 3 + 9);
-  HostMover in(nullptr, true);
+  if (b->s_copy == nullptr) {
+    HIP_CHECK(hipStreamCreateWithFlags(&b->s_copy, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&b->s_exec, hipStreamNonBlocking));
+  }
+  // an array handed over twice is staged once: the later entry takes the earlier one's device copy - and its stage,
+  // if that one crosses in full (a stage-3 entry shares only with a full copy, never the other way round)
+  int same_as[nin];
+  bool whole[nin];                       // crosses in full even at stage 3
+  for (size_t i = 0; i < nin; ++i) whole[i] = ins[i].stage != 3 || ins[i].n == plane;
   for (size_t i = 0; i < nin; ++i) {
     if (ins[i].host == nullptr) throw OhxError("OHXBoosterRun1: a required field pointer is NULL");
+    same_as[i] = -1;
+    for (size_t q = 0; q < i && same_as[i] < 0; ++q)
+      if (ins[q].host == ins[i].host && ins[q].n == ins[i].n && same_as[q] < 0 && ins[q].stage != 3) same_as[i] = (int)q;
+    if (same_as[i] >= 0) {
+      *ins[i].dev = b->d_run1_stage[(size_t)same_as[i]].p;
+      // the walk reads it too: it crosses with the walk's inputs, in full (ins[q].n == vol keeps it whole below)
+      if (ins[i].stage == 3 && ins[(size_t)same_as[i]].stage == 2) {
+        ins[(size_t)same_as[i]].stage = 3;
+        whole[(size_t)same_as[i]] = true;
+      }
+      continue;
+    }
     b->d_run1_stage[i].ensure(ins[i].n);
-    in.add(b->d_run1_stage[i].p, ins[i].host, ins[i].n);
     *ins[i].dev = b->d_run1_stage[i].p;
   }
-  in.go();
+  struct Feed : Run1Feed {
+    BoosterObj* b;
+    In* ins;
+    const int* same_as;
+    const bool* whole;
+    size_t plane, km;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    void stage(int which, int k1, int k2) {
+      HostMover in(b->s_copy, true);
+      for (size_t i = 0; i < nin; ++i) {
+        if (ins[i].stage != which || same_as[i] >= 0) continue;
+        float* dev = b->d_run1_stage[i].p;
+        if (!whole[i]) {
+          if (k2 >= k1) in.add_slice(dev + plane * (size_t)(k1 - 1), ins[i].host, plane * km, plane * (size_t)(k1 - 1), plane * (size_t)(k2 - k1 + 1));
+        } else {
+          in.add(dev, ins[i].host, ins[i].n);
+        }
+      }
+      in.go();
+    }
+    hipEvent_t slab_inputs() override {
+      stage(0, 0, 0);
+      HIP_CHECK(hipEventRecord(ev[0], b->s_copy));
+      return ev[0];
+    }
+    hipEvent_t prep_inputs() override {
+      stage(1, 0, 0);
+      HIP_CHECK(hipEventRecord(ev[1], b->s_copy));
+      return ev[1];
+    }
+    void rest(int k1, int k2, hipEvent_t* walk_inputs, hipEvent_t* post_inputs) override {
+      stage(3, k1, k2);             // what the walk waits for goes first ...
+      HIP_CHECK(hipEventRecord(ev[2], b->s_copy));
+      stage(2, 0, 0);               // ... the model's T, Q and the default OH are wanted by the last kernel of the tick
+      HIP_CHECK(hipEventRecord(ev[3], b->s_copy));
+      *walk_inputs = ev[2];
+      *post_inputs = ev[3];
+    }
+  } feed;
+  feed.b = b;
+  feed.ins = ins;
+  feed.same_as = same_as;
+  feed.whole = whole;
+  feed.plane = plane;
+  feed.km = (size_t)h.km;
+  while (b->run1_feed_events.size() < 4) {
+    hipEvent_t e;
+    // with timing: such a record is a packet with a completion signal of its own.  Recorded without, the waits on these
+    // events were released by the NEXT copy's end (the feature kernels started when list B had landed, 80 us late:
+    // profiles/r05_sweeps.txt)
+    HIP_CHECK(hipEventCreate(&e));
+    b->run1_feed_events.push_back(e);
+  }
+  for (int i = 0; i < 4; ++i) feed.ev[i] = b->run1_feed_events[(size_t)i];
   if (h.oh == nullptr) throw OhxError("OHXBoosterRun1: oh is NULL");
   b->d_run1_stage[nin].ensure(vol);
   d.oh = b->d_run1_stage[nin].p;
@@ -1893,15 +2019,23 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
     b->d_run1_stage[nin + 3 + i].ensure(outs[i].n);
     *outs[i].dev = b->d_run1_stage[nin + 3 + i].p;
   }
-  run1_device(*b, d, nullptr);
-  HostMover back(nullptr, false);
+  hipStream_t main = b->s_exec;
+  try {
+    run1_device(*b, d, main, &feed);
+  } catch (...) {
+    // nothing of this call may still be reading the caller's arrays when it returns, error or not
+    (void)hipStreamSynchronize(b->s_copy);
+    (void)hipStreamSynchronize(main);
+    throw;
+  }
+  HostMover back(main, false);
   back.add(h.oh, d.oh, vol);
   if (h.ndwet) back.add(h.ndwet, d.ndwet, vol);
   if (h.oh_boost) back.add(h.oh_boost, d.oh_boost, vol);
   for (size_t i = 0; i < nout; ++i)
     if (outs[i].host) back.add(outs[i].host, *outs[i].dev, outs[i].n);
   back.go();
-  raise_flag_errors(*b, nullptr);          // waits for the stream: the outputs are in the caller's arrays
+  raise_flag_errors(*b, main);          // waits for the stream: the outputs are in the caller's arrays
   API_END();
 }
 

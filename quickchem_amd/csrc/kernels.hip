@@ -1747,6 +1747,51 @@ __global__ __launch_bounds__(kBlock) void feature_column_sums_reg_kernel(PrepArg
   }
 }
 
+// The same for a SMALL plane (a GEOS rank's block: 48 x 24 = 1 152 columns): a WAVE per column and field, a lane per
+// level (two with more than 64 levels).  With a thread per column a rank's block is 18 waves on the whole chip, each
+// with 72 strided loads and 2 628 dependent additions in front of it: 87 us of a 370 us tick (profiles/r05_sweeps.txt).
+// Here every lane runs its own two chains over the column in LDS - SUM(x(1:k)) and SUM(x(k:km)), each from zero in
+// ascending level order, the additions the reference's SUM makes (:1468-1478) - 72 steps for all levels at once.
+constexpr int kColWaveMaxKm = 128;
+__global__ __launch_bounds__(kBlock) void feature_column_sums_wave_kernel(PrepArgs a, const float* __restrict__ aod) {
+#pragma clang fp contract(off)
+  __shared__ float xs[kWavesPerBlock][kColWaveMaxKm];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const uint64_t plane = (uint64_t)a.im * (uint64_t)a.jm;
+  const uint64_t ncols = a.ncols ? a.ncols : plane;
+  const uint64_t item = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (item >= ncols) return;
+  const uint64_t col = a.col0 + item;
+  const float* src = (blockIdx.y == 0 ? a.tauclw : (blockIdx.y == 1 ? a.taucli : aod)) + col;
+  float* up = (blockIdx.y == 0 ? a.tauclwup : (blockIdx.y == 1 ? a.taucliup : a.aodup)) + col;
+  float* dn = (blockIdx.y == 0 ? a.tauclwdn : (blockIdx.y == 1 ? a.tauclidn : a.aoddn)) + col;
+  const int km = a.km;
+  const int ka = lane, kb = lane + kWave;                 // this lane's one or two levels
+  if (ka < km) xs[wave][ka] = src[plane * (uint64_t)ka];
+  if (kb < km) xs[wave][kb] = src[plane * (uint64_t)kb];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float up_a = 0.0f, dn_a = 0.0f, up_b = 0.0f, dn_b = 0.0f;
+#pragma unroll 8
+  for (int kk = 0; kk < km; ++kk) {
+    const float v = xs[wave][kk];                         // every lane the same word: a broadcast
+    if (kk <= ka) up_a = up_a + v;
+    if (kk >= ka) dn_a = dn_a + v;
+    if (kk <= kb) up_b = up_b + v;
+    if (kk >= kb) dn_b = dn_b + v;
+  }
+  if (ka < km) {
+    up[plane * (uint64_t)ka] = up_a;
+    dn[plane * (uint64_t)ka] = dn_a;
+  }
+  if (kb < km) {
+    up[plane * (uint64_t)kb] = up_b;
+    dn[plane * (uint64_t)kb] = dn_b;
+  }
+}
+
 // ksubcount = max over columns of COUNT(pl > tropp | tropp_min) (:275-298)
 __global__ __launch_bounds__(kBlock) void k_slab_kernel(SlabArgs a) {
 #pragma clang fp contract(off)
@@ -2465,6 +2510,11 @@ hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_
   if (a.col0 + a.ncols > plane || a.km > 65535) return hipErrorInvalidValue;
   const uint64_t ncols = a.ncols ? a.ncols : plane;
   hipLaunchKernelGGL(feature_pointwise_kernel, level_grid(ncols, a.km), dim3(kBlock), 0, stream, a, aod_scratch);
+  if (ncols <= 8192 && a.km <= kColWaveMaxKm) {      // a rank's block: a wave per column
+    hipLaunchKernelGGL(feature_column_sums_wave_kernel, dim3((unsigned)((ncols + kWavesPerBlock - 1) / kWavesPerBlock), 3),
+                       dim3(kBlock), 0, stream, a, (const float*)aod_scratch);
+    return hipGetLastError();
+  }
   if (a.km == 72) {        // GEOS's 72 levels: the column in registers
     hipLaunchKernelGGL(feature_column_sums_reg_kernel<72>, dim3((unsigned)((ncols + kBlock - 1) / kBlock), 3), dim3(kBlock), 0,
                        stream, a, (const float*)aod_scratch);
@@ -2525,12 +2575,13 @@ __global__ __launch_bounds__(kBlock) void copy_arrays_kernel(CopyList l) {
 }
 }  // namespace
 
-hipError_t launch_copy_arrays(const CopyList& l, hipStream_t stream) {
+hipError_t launch_copy_arrays(const CopyList& l, hipStream_t stream, uint32_t max_blocks_per_array) {
   if (l.count == 0) return hipSuccess;
   uint64_t longest = 0;
   for (uint32_t a = 0; a < l.count; ++a) longest = l.n[a] > longest ? l.n[a] : longest;
   uint64_t blocks = (longest / 4 + kBlock - 1) / kBlock;
-  if (blocks > 2048) blocks = 2048;
+  if (max_blocks_per_array == 0) max_blocks_per_array = 2048;
+  if (blocks > max_blocks_per_array) blocks = max_blocks_per_array;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(copy_arrays_kernel, dim3((unsigned)blocks, l.count), dim3(kBlock), 0, stream, l);
   return hipGetLastError();
