@@ -311,7 +311,13 @@ HostRegistry g_host_registry;
 // copy_arrays_kernel (the GPU reads or writes the caller's memory over PCIe itself) as long as the whole list is
 // small - a rank-sized block, where forty separate copies cost forty fixed prices; big lists and arrays that are not
 // registered go through hipMemcpyAsync.
-std::atomic<uint32_t> g_copy_blocks{0};      // experiment knob "ohx_copy_blocks": blocks per array of copy_arrays_kernel (0 = up to 2048)
+// blocks of a launch of copy_arrays_kernel, over all its arrays ("ohx_copy_blocks"; 0 = as many as an array has 1 KiB
+// pieces, up to 2 048 per array).  Sixty-four: a copy kernel that fills the chip with waves waiting on PCIe is slower at
+// moving a rank's arrays (88 against 72 us per 3.7 MB list) and - with megabytes of reads queued on the link - keeps
+// every other queue's kernels from STARTING until it is done (the command processor fetches their packets and
+// arguments over the same link); a 48 x 24 x 72 tick 0.349 / 0.345 / 0.328 / 0.339 / 0.389 ms at 256 / 128 / 64 / 32 / 16
+// blocks, 0.398 with a block per KiB (profiles/r05_sweeps.txt)
+std::atomic<uint32_t> g_copy_blocks{64};
 struct HostMover {
   static constexpr size_t kKernelBytesMax = 64u << 20;
   CopyList list;
@@ -1540,7 +1546,8 @@ struct Run1Feed {
   // each enqueues copies on the feed's own stream and returns an event recorded behind them
   virtual hipEvent_t slab_inputs() = 0;                              // PLE and TROPP of the model
   virtual hipEvent_t prep_inputs() = 0;                              // what the feature engineering reads
-  virtual void rest(int k1, int k2, hipEvent_t* walk_inputs, hipEvent_t* post_inputs) = 0;      // 1-based slab levels
+  virtual hipEvent_t walk_inputs(int k1, int k2) = 0;                // 1-based slab levels
+  virtual hipEvent_t post_inputs() = 0;                              // what the tick's last kernel reads; asked for once the walk is enqueued
 };
 
 static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream, Run1Feed* feed = nullptr) {
@@ -1591,7 +1598,13 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   // host form: PLE and TROPP cross first, and the slab count is enqueued behind them before anything else is even
   // listed - its answer is back on the host while the features' inputs are still crossing, so the walk's own inputs
   // follow them over PCIe without a gap
-  if (feed != nullptr) HIP_CHECK(hipStreamWaitEvent(side, feed->slab_inputs(), 0));
+  hipEvent_t prep_inputs = nullptr;
+  if (feed != nullptr) {
+    HIP_CHECK(hipStreamWaitEvent(side, feed->slab_inputs(), 0));
+    // ... and the next list is handed to the copy stream before this thread turns to anything else: the six calls that
+    // enqueue the slab count took it 50 us, during which the link stood idle (profiles/r05_sweeps.txt)
+    prep_inputs = feed->prep_inputs();
+  }
 
   SlabArgs sa;
   sa.im = r.im; sa.jm = r.jm; sa.km = r.km;
@@ -1602,11 +1615,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   HIP_CHECK(hipMemcpyAsync(b.h_slab.p, b.d_slab.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, side));
   HIP_CHECK(hipEventRecord(b.run1_slab, side));
   HIP_CHECK(hipMemsetAsync(oh_ml, 0, vol * sizeof(float), side));            // self%OH_ML(:,:,:) = 0.0 (:1559)
-  hipEvent_t prep_inputs = nullptr;
-  if (feed != nullptr) {
-    prep_inputs = feed->prep_inputs();
-    HIP_CHECK(hipStreamWaitEvent(stream, prep_inputs, 0));
-  }
+  if (prep_inputs != nullptr) HIP_CHECK(hipStreamWaitEvent(stream, prep_inputs, 0));
 
   // pieces: as many as the slab's tiles make whole launches of the ring kernel (at its most, all km levels), of whole
   // rows of bricks (four j); the pieces' extents do not depend on the slab count, which is not known yet
@@ -1680,11 +1689,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   if (r.k1) *r.k1 = k1;
   if (r.k2) *r.k2 = k2;
   hipEvent_t post_inputs = nullptr;
-  if (feed != nullptr) {
-    hipEvent_t walk_inputs = nullptr;
-    feed->rest(k1, k2, &walk_inputs, &post_inputs);
-    HIP_CHECK(hipStreamWaitEvent(stream, walk_inputs, 0));
-  }
+  if (feed != nullptr) HIP_CHECK(hipStreamWaitEvent(stream, feed->walk_inputs(k1, k2), 0));
 
   const float* fields[27] = {r.lat_deg, pl_bst, r.t_bst, r.no2, r.o3, r.ch4, r.co, r.isop, r.acet, r.c2h6, r.c3h8,
                              r.prpe, r.alk4, r.mp, r.h2o2, tauclwdn, tauclidn, taucliup, tauclwup, r.cloud, r.qv,
@@ -1723,6 +1728,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
       HIP_CHECK(launch_predict_fields(kind, device_forest(b), fa, b.dev.num_cus, stream, tune));
       if (deferring && q + 1 == npieces) defer_look(b, slab_rows, stream);
     }
+    if (feed != nullptr && post_inputs == nullptr) post_inputs = feed->post_inputs();      // behind the (first) walk's launch
     if (npieces == 1) {
       if (post_inputs != nullptr) HIP_CHECK(hipStreamWaitEvent(stream, post_inputs, 0));
       post_piece(0, stream);
@@ -1968,13 +1974,15 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
       HIP_CHECK(hipEventRecord(ev[1], b->s_copy));
       return ev[1];
     }
-    void rest(int k1, int k2, hipEvent_t* walk_inputs, hipEvent_t* post_inputs) override {
-      stage(3, k1, k2);             // what the walk waits for goes first ...
+    hipEvent_t walk_inputs(int k1, int k2) override {
+      stage(3, k1, k2);
       HIP_CHECK(hipEventRecord(ev[2], b->s_copy));
-      stage(2, 0, 0);               // ... the model's T, Q and the default OH are wanted by the last kernel of the tick
+      return ev[2];
+    }
+    hipEvent_t post_inputs() override {          // the model's T, Q and the default OH cross under the walk
+      stage(2, 0, 0);
       HIP_CHECK(hipEventRecord(ev[3], b->s_copy));
-      *walk_inputs = ev[2];
-      *post_inputs = ev[3];
+      return ev[3];
     }
   } feed;
   feed.b = b;

@@ -2575,13 +2575,14 @@ __global__ __launch_bounds__(kBlock) void copy_arrays_kernel(CopyList l) {
 }
 }  // namespace
 
-hipError_t launch_copy_arrays(const CopyList& l, hipStream_t stream, uint32_t max_blocks_per_array) {
+hipError_t launch_copy_arrays(const CopyList& l, hipStream_t stream, uint32_t max_blocks) {
   if (l.count == 0) return hipSuccess;
   uint64_t longest = 0;
   for (uint32_t a = 0; a < l.count; ++a) longest = l.n[a] > longest ? l.n[a] : longest;
   uint64_t blocks = (longest / 4 + kBlock - 1) / kBlock;
-  if (max_blocks_per_array == 0) max_blocks_per_array = 2048;
-  if (blocks > max_blocks_per_array) blocks = max_blocks_per_array;
+  // `max_blocks` counts the launch's blocks over all arrays (0 = up to 2 048 per array)
+  const uint64_t per_array = max_blocks == 0 ? 2048 : (max_blocks / l.count > 0 ? max_blocks / l.count : 1);
+  if (blocks > per_array) blocks = per_array;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(copy_arrays_kernel, dim3((unsigned)blocks, l.count), dim3(kBlock), 0, stream, l);
   return hipGetLastError();

@@ -332,7 +332,7 @@ struct CopyList {
   uint64_t n[kCopyListMax];     // floats
   uint32_t count = 0;
 };
-hipError_t launch_copy_arrays(const CopyList& l, hipStream_t stream, uint32_t max_blocks_per_array = 0);
+hipError_t launch_copy_arrays(const CopyList& l, hipStream_t stream, uint32_t max_blocks = 0);
 
 hipError_t launch_scan_dense(const float* data, uint64_t count, float missing, uint32_t* flags, hipStream_t stream);
 // Level-size search (capi.cpp infer_level_size): block (x, y) tests whether column cols.col[y] repeats with
