@@ -107,6 +107,35 @@ def cpu_model_name():
     return "unknown"
 
 
+def cpu_topology():
+    """-> (hardware threads this process may run on, physical cores among them, sockets), from /proc/cpuinfo and the
+    affinity mask: os.cpu_count() counts hardware THREADS, and a line that calls them cores is off by the SMT factor."""
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    cores, sockets, cpu, phys, core = set(), set(), None, None, None
+    try:
+        for line in list(open("/proc/cpuinfo")) + ["\n"]:
+            key, _, val = line.partition(":")
+            key = key.strip()
+            if key == "processor":
+                cpu, phys, core = int(val), None, None
+            elif key == "physical id":
+                phys = int(val)
+            elif key == "core id":
+                core = int(val)
+            elif not line.strip() and cpu is not None:
+                if cpu in allowed:
+                    cores.add((phys, core if core is not None else cpu))
+                    sockets.add(phys)
+                cpu = None
+    except (OSError, ValueError):
+        pass
+    threads = len(allowed)
+    return threads, (len(cores) or threads), (len(sockets) or 1)
+
+
 def kernel_source_hash():
     """Identifies the kernels a committed PMC measurement was taken on (profiles/*_traffic.json)."""
     import hashlib
@@ -171,7 +200,7 @@ def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
     from quickchem_amd import capi, synth
     im, jm, km = grid
     plane = im * jm
-    cores = os.cpu_count() or 1
+    cores, phys_cores, sockets = cpu_topology()      # `cores` below = hardware threads used (OMP_NUM_THREADS)
     dev = out_dev.device
     fields = []
     for feat in range(synth.NFEAT):
@@ -201,13 +230,15 @@ def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
     if ulp > 2:
         raise SystemExit(f"bench: GPU OH differs from the Fortran CPU path by {ulp} ulp on the cpu_baseline sample")
     del fields, oh_gpu
-    base = {"value": n / steady, "unit": "gridcells/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+    base = {"value": n / steady, "unit": "gridcells/s", "cores": phys_cores, "threads": cores, "sockets": sockets,
+            "kind": "port", "cpu_model": cpu_model_name(),
             "sample": f"first {levels} of {km} levels ({n} gridcells) of the batch: oracle/lib/oh_mock_driver_oracle = the "
                       f"Fortran host's predict_OH_with_XGB (SoA->AoS gather, XGDMatrixCreateFromMat, XGBoosterPredict, "
                       f"10**pred; OH_GridCompMod.F90:308-374) linked against oracle/xgb_oracle.c, OMP_NUM_THREADS={cores} "
+                      f"(every hardware thread of the {phys_cores} cores on {sockets} socket(s)) "
                       f"pinned (OMP_PROC_BIND=spread OMP_PLACES=cores; gather and 10** single-threaded as in the "
                       f"reference); {len(t_all)} ticks in one process, value = the fastest tick after the first "
-                      f"({steady:.2f} s); libxgboost 1.6.0 itself is not available here.  All cores give about ten times "
+                      f"({steady:.2f} s); libxgboost 1.6.0 itself is not available here.  All threads give about ten times "
                       f"one thread, not {cores} times: the walk is bound by memory latency on the booster's 112 MB of raw "
                       f"nodes, far beyond the caches - a baseline, not a measure of the GPU kernel (that is roofline.frac)",
             "ticks_s": [round(t, 4) for t in t_all],

@@ -1592,7 +1592,10 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
     HIP_CHECK(hipEventCreateWithFlags(&b.run1_join, hipEventDisableTiming));
   }
   b.h_slab.ensure(2);
-  hipStream_t side = b.s_run1;
+  // the host form of a rank's block may be told to use fewer queues (experiment knob OHX_RUN1_STREAMS=1|2|3, read once):
+  // many ranks share a GPU, and every stream of every process is a hardware queue the scheduler has to map
+  static const int nstreams = [] { const char* e = getenv("OHX_RUN1_STREAMS"); return e ? atoi(e) : 3; }();
+  hipStream_t side = (feed != nullptr && nstreams < 3) ? stream : b.s_run1;
   HIP_CHECK(hipEventRecord(b.run1_fork, stream));            // the side stream starts behind what the caller has enqueued
   HIP_CHECK(hipStreamWaitEvent(side, b.run1_fork, 0));
   // host form: PLE and TROPP cross first, and the slab count is enqueued behind them before anything else is even
@@ -2027,7 +2030,8 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
     b->d_run1_stage[nin + 3 + i].ensure(outs[i].n);
     *outs[i].dev = b->d_run1_stage[nin + 3 + i].p;
   }
-  hipStream_t main = b->s_exec;
+  static const int nstreams = [] { const char* e = getenv("OHX_RUN1_STREAMS"); return e ? atoi(e) : 3; }();
+  hipStream_t main = nstreams == 1 ? b->s_copy : b->s_exec;
   try {
     run1_device(*b, d, main, &feed);
   } catch (...) {

@@ -93,6 +93,8 @@ def child(args):
         d.free()
         ticks["reference"].append(time.perf_counter() - t0)
         ends["reference"].append(time.time())
+        if tick == 0:
+            meet("reference")                              # the first tick loads the model file; the others run together
     t_ref1 = time.time()
     p = p.copy()
     ref_sum = float(np.float64(p).sum())
