@@ -815,7 +815,8 @@ def main():
     rounds = int(knob.get("ohx_ring_rounds", capi.RING_ROUNDS_DEFAULT)) if "ring" in symbol else int(knob.get("ohx_launches_per_residency", 2))
     if "ring" in symbol and (args.shuffle or args.consecutive):      # rows not known to lie on a grid keep short launches
         clustered = args.shuffle and "ohx_cluster=off" not in args.param
-        rounds = min(rounds, capi.RING_ROUNDS_PERMUTED if clustered else capi.RING_ROUNDS_NO_GRID) if rounds > 0 else rounds
+        cap = capi.RING_ROUNDS_PERMUTED if clustered else capi.RING_ROUNDS_NO_GRID
+        rounds = min(rounds, cap) if rounds > 0 else cap
     ring_cus = cus - int(knob.get("ohx_reserve_cus", 0))
     per_launch = (ring_cus * 16 if "ring" in symbol else cus * 20) * rounds if rounds > 0 else 1 << 62
     launches_per_step = sum(-(-((hi - lo + 63) // 64) // per_launch) for lo, hi in pieces)

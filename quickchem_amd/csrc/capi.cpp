@@ -1653,6 +1653,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   pa.aodup = aodup; pa.aoddn = aoddn; pa.strato3 = strato3;
   auto prep_piece = [&](int q, hipStream_t s) {
     PrepArgs p = pa;
+    p.beside_a_walk = q >= 2 ? 1 : 0;        // pieces 0 and 1 are prepared before the first walk starts
     if (npieces > 1) {
       p.col0 = (uint64_t)j_lo[(size_t)q] * (uint64_t)r.im;
       p.ncols = (uint64_t)(j_lo[(size_t)q + 1] - j_lo[(size_t)q]) * (uint64_t)r.im;

@@ -221,12 +221,39 @@ __device__ __forceinline__ uint64_t level_floats(const FieldsArgs& a, uint64_t p
   return a.level_stride ? a.level_stride : plane;
 }
 
+// 10.0**x for a float32 x (OH_ML = 10.0 ** xx_pred, OH_GridCompMod.F90:369), rounded ONCE from a double that is good to
+// 2e-14: x log2(10) in double, split into an integer and |f| <= 1/2, 2**f as its Taylor polynomial of degree 11 (last
+// term 6e-15), scaled by v_ldexp_f64.  It agrees with a correctly rounded powf wherever the double does not sit within
+// 2e-14 of a float32 rounding boundary (3 in 10 million values; 0 of 20 000 against 60-digit arithmetic on the host).
+// Until round 4 this was (float)pow(10.0, (double)x): the library's general double pow held the fused ring kernel at 121
+// vector registers - every register of the CU, four waves per SIMD at 128 - where the walk itself needs 88 (r5): with it
+// nothing could run beside a fused walk (OH Run1's streaming kernels, a collective's kernels).
+__device__ __forceinline__ float pow10_f32(float x) {
+  double y = (double)x * 3.321928094887362;           // log2(10)
+  y = y < -1100.0 ? -1100.0 : (y > 1100.0 ? 1100.0 : y);     // +-inf -> 0 / inf below; NaN passes through
+  const double n = __builtin_rint(y);
+  const double f = y - n;                             // exact
+  double p = 4.44553827187081e-10;                    // ln(2)**k / k!, k = 11 .. 0
+  p = __builtin_fma(p, f, 7.054911620801121e-09);
+  p = __builtin_fma(p, f, 1.0178086009239696e-07);
+  p = __builtin_fma(p, f, 1.3215486790144305e-06);
+  p = __builtin_fma(p, f, 1.5252733804059838e-05);
+  p = __builtin_fma(p, f, 0.00015403530393381606);
+  p = __builtin_fma(p, f, 0.0013333558146428441);
+  p = __builtin_fma(p, f, 0.009618129107628477);
+  p = __builtin_fma(p, f, 0.055504108664821576);
+  p = __builtin_fma(p, f, 0.2402265069591007);
+  p = __builtin_fma(p, f, 0.6931471805599453);
+  p = __builtin_fma(p, f, 1.0);
+  return (float)__builtin_ldexp(p, (int)n);
+}
+
 // what the fused path stores for a gridcell: the margin (optional) and 10**margin * OHscale (:369, :1569)
 __device__ __forceinline__ void store_oh(const FieldsArgs& a, float* __restrict__ out, float* __restrict__ margin_out,
                                          uint64_t slab_out, uint64_t m, uint64_t at3, float acc) {
   if (margin_out) margin_out[m] = acc;
   float oh = acc;
-  if (a.apply_pow10) oh = (float)pow(10.0, (double)acc);      // 10.0**x rounded once from double: agrees with a correctly rounded powf
+  if (a.apply_pow10) oh = pow10_f32(acc);
   oh = oh * a.scale;
   out[slab_out + at3] = oh;
 }
@@ -2066,7 +2093,7 @@ hipError_t launch_rows_ring(const DeviceForest& fr, PredictArgs a, int num_cus, 
   // (through the permutation: 47.4 ms at 16, 45.9 at 4; 64 consecutive rows per wave: 34.05 at 16, 34.5 at 4)
   int rounds = tune.ring_rounds;
   const int no_grid = a.perm != nullptr ? kRingRoundsPermuted : kRingRoundsNoGrid;
-  if (a.shape.im == 0 && rounds > no_grid) rounds = no_grid;
+  if (a.shape.im == 0 && (rounds <= 0 || rounds > no_grid)) rounds = no_grid;      // (0 = one launch: for rows on a grid only)
   const uint64_t per_launch = rounds <= 0 ? ntiles : grid * kRingWaves * (uint64_t)rounds;
   TrainCursor train(stream, tune);
   for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
@@ -2510,7 +2537,9 @@ hipError_t launch_feature_prep(const PrepArgs& a, float* aod_scratch, hipStream_
   if (a.col0 + a.ncols > plane || a.km > 65535) return hipErrorInvalidValue;
   const uint64_t ncols = a.ncols ? a.ncols : plane;
   hipLaunchKernelGGL(feature_pointwise_kernel, level_grid(ncols, a.km), dim3(kBlock), 0, stream, a, aod_scratch);
-  if (ncols <= 8192 && a.km <= kColWaveMaxKm) {      // a rank's block: a wave per column
+  // a rank's block: a wave per column.  Also for a piece whose features are computed beside another piece's walk: the
+  // kernel with a column in registers needs 143 of them, this one 26 and 2 KB of LDS
+  if ((ncols <= 8192 || a.beside_a_walk) && a.km <= kColWaveMaxKm) {
     hipLaunchKernelGGL(feature_column_sums_wave_kernel, dim3((unsigned)((ncols + kWavesPerBlock - 1) / kWavesPerBlock), 3),
                        dim3(kBlock), 0, stream, a, (const float*)aod_scratch);
     return hipGetLastError();

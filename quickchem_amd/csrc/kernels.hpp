@@ -252,6 +252,7 @@ struct FieldsArgs {
 struct PrepArgs {
   int im = 0, jm = 0, km = 0;
   uint64_t col0 = 0, ncols = 0;      // columns [col0, col0 + ncols) of the im * jm only (ncols 0 = all): Run1's pieces
+  int beside_a_walk = 0;             // the kernels must fit in what a ring block leaves of a CU (64 VGPRs a wave, 4 KB of LDS)
   const float *ple_bst = nullptr, *zle_bst = nullptr, *tauclw = nullptr, *taucli = nullptr;
   const float* sca[7] = {};
   const float *gmito3 = nullptr, *gmitto3 = nullptr;
