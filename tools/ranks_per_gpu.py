@@ -199,7 +199,12 @@ def parent(args):
             c1 = min(r["tick_ends"][mode][-1] for r in ranks)
             cells = sum(r["rows"] * sum(1 for e in r["tick_ends"][mode][1:] if c0 < e <= c1) for r in ranks)
             entry[mode] = {"first_tick_s": {"max": max(first), "min": min(first)},
-                           "tick_ms": {"p50": pct(later, 0.5) * 1e3, "p95": pct(later, 0.95) * 1e3, "max": max(later) * 1e3},
+                           "tick_ms": {"p50": pct(later, 0.5) * 1e3, "p95": pct(later, 0.95) * 1e3, "max": max(later) * 1e3,
+                                       "mean": sum(later) / len(later) * 1e3,
+                                       "deciles": [round(pct(later, q / 10) * 1e3, 3) for q in range(1, 10)],
+                                       "p99": pct(later, 0.99) * 1e3},
+                           # the shape of the tail: rank 0's ticks in order (the first sixty after the first)
+                           "rank0_ticks_ms": [round(t * 1e3, 3) for t in ranks[0]["ticks_s"][mode][1:61]],
                            "common_window_s": c1 - c0,
                            "aggregate_gridcells_per_s": cells / (c1 - c0) if c1 > c0 else None}
         result["by_ranks"][str(P)] = entry
