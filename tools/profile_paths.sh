@@ -14,7 +14,7 @@ for path in fields run1; do
   rm -rf $O/trace_$path
   timeout -k 10 600 python3 bench.py --path $path --steps 10 --warmup 3 > $O/bench_${path}.log 2>&1 || exit 1
   grep "^{\"metric\"" $O/bench_${path}.log | tail -1 > $O/bench_${path}.json
-  tools/pmc.sh ${tag}_$path --path $path > /dev/null 2>&1
+  PMC_SETS=base tools/pmc.sh ${tag}_$path --path $path > /dev/null 2>&1
   cp gpurun_out/pmc_${tag}_$path/summary.txt $O/pmc_${path}.txt
   rm -rf gpurun_out/pmc_${tag}_$path/*/
   echo "$path done"
