@@ -831,9 +831,9 @@ def main():
     plain = (not args.shuffle and not args.missing_ppm and args.trees == 100 and args.depth == 18)
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and plain:
         cpu = cpu_baseline(model.image, grid, booster, out_local, args.cpu_seconds)
-        # and bit for bit on the raw margins, oracle through ctypes, first 2**18 rows
+        # and bit for bit on the raw margins, oracle through ctypes, first 2**20 rows
         lib = capi.declare_xgb_api(C.CDLL(os.path.join(ROOT, "oracle", "lib", "liboracle_xgb.so")))
-        n_chk = min(n_local, 1 << 18)
+        n_chk = min(n_local, 1 << 20)
         ob = capi.Booster(model_buffer=model.image, lib=lib)
         od = capi.DMatrix(rows[:n_chk].cpu().numpy(), missing=synth.XX_MISS, lib=lib)
         want = ob.predict(od)
@@ -873,7 +873,7 @@ def main():
                           "build_s": round(t_model, 2)},
                 "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid), "grid_known_to_library": list(dmats[0].grid()), "verified": verified,
                 "verified_against": ("the whole timed output, bit for bit, against the `wide` kernel (other node format, no LDS tile, no grid hint); "
-                                     "the CPU oracle sees the first 2^18 rows and 2^18 rows drawn from the whole batch "
+                                     "the CPU oracle sees the first 2^20 rows and 2^20 rows drawn from the whole batch "
                                      "(cpu_baseline.margins_bit_identical_on_first_rows / _on_random_rows)") if verified else None,
                 "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
                 "gather_via": (args.gather if (world > 1 or force_dist) else None),

@@ -110,6 +110,13 @@ def test_stale_handles_under_address_sanitizer(tmp_path):
     assert r.returncode == 0 and "handle_abuse: ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
+def test_unregistering_what_was_never_registered_is_not_an_error():
+    """OHXUnregisterHost (include/ohxgb.h): a caller may say "this array is going away" about any array."""
+    lib = capi.load_library()
+    a = np.zeros(16, dtype=np.float32)
+    assert lib.OHXUnregisterHost(a.ctypes.data) == 0 and lib.OHXUnregisterHost(None) == 0
+
+
 def test_compute_without_gpu_fails_loudly():
     """No CPU fallback: where no HIP device is usable every compute entry point returns -1."""
     import torch

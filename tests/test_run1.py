@@ -342,6 +342,23 @@ def test_host_forms_with_registered_arrays(small_model):
                     assert got[k] == v
             if tick == 1:
                 capi.check(b.lib, b.lib.OHXReleaseScratch())
+        # (r5) one array leaves on its own - the caller is about to free it - and comes back: the tick after registers it
+        # again; an array the library never saw, and NULL, are not errors; an array passed twice (the model's T is also
+        # Boost's T under ONLINE_INST) crosses once and changes nothing
+        capi.check(b.lib, b.lib.OHXUnregisterHost(call["keep"]["t_mod"].ctypes.data))
+        capi.check(b.lib, b.lib.OHXUnregisterHost(np.zeros(8, dtype=np.float32).ctypes.data))
+        capi.check(b.lib, b.lib.OHXUnregisterHost(None))
+        got = b.run1_call(call)
+        assert np.array_equal(helpers.bits(got["oh"]), helpers.bits(plain["oh"]))
+        same_t = b.run1_prepare(dict(st, t_bst=st["t_mod"], qv=st["q_mod"], ple_bst=st["ple_mod"]), dynamic_k_range=True)
+        same_t["args"].t_bst = same_t["args"].t_mod
+        same_t["args"].qv = same_t["args"].q_mod
+        same_t["args"].ple_bst = same_t["args"].ple_mod
+        aliased = b.run1_call(same_t)
+        want_aliased = oracle_run1(small_model.image, dict(st, t_bst=st["t_mod"], qv=st["q_mod"], ple_bst=st["ple_mod"]),
+                                   dynamic_k_range=True)
+        assert np.array_equal(helpers.bits(aliased["ndwet"]), helpers.bits(want_aliased["ndwet"]))
+        assert helpers.ulp_diff(aliased["oh"], want_aliased["oh"]).max() <= 3
         # the post-processing of a tick that skips Boost, host form
         im, jm, km = grid
         flat = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32).T)      # noqa: E731
