@@ -474,8 +474,39 @@ def measured_traffic(grid_name, kernel, model_nodes):
             if not why.startswith("profiles/"):       # name the newest such file, not the oldest
                 why = f"profiles/{name} was measured on other kernel sources ({t.get('kernel_source_hash')} != {have})"
             continue
+        measured_traffic.counters = t.get("counters_per_step")
         return t.get("traffic_bytes_per_step"), f"profiles/{name}"
     return None, why
+
+
+measured_traffic.counters = None       # of the file measured_traffic() accepted: what unit_busy() prices
+
+# what a wave64 vector instruction of the walk's step costs a SIMD to issue with four waves on it, in cycles of the
+# nominal 2.4 GHz: measured, tools/valu_issue_microbench.hip (profiles/r05_valu_issue_microbench.txt)
+VALU_CYCLES_PER_INSTRUCTION = 3.90
+VALU_CYCLES_CLOCK_HZ = 2.4e9
+
+
+def unit_busy(kernel_s, dev):
+    """roofline.valu_issue and roofline.ta_busy: how busy the two units are that the walk is bound by, from the counters
+    of the committed --pmc passes (same file and same source-hash rule as roofline.traffic; per step) and this run's
+    kernel time.  valu_issue = vector instructions x the MEASURED issue cost of the step's instruction mix / (SIMDs x
+    time); ta_busy = the texture addressers' busy cycles / the CUs' busy cycles.  (None, None) without a matching file."""
+    import torch
+    c = measured_traffic.counters
+    if not c or not c.get("SQ_INSTS_VALU") or not c.get("TA_TA_BUSY_sum") or not c.get("SQ_BUSY_CU_CYCLES"):
+        return None, None
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    valu_s = c["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INSTRUCTION / VALU_CYCLES_CLOCK_HZ / (4 * cus)
+    valu = {"instructions_per_step": c["SQ_INSTS_VALU"], "cycles_per_instruction": VALU_CYCLES_PER_INSTRUCTION,
+            "cycles_per_instruction_source": "measured: the walk's 14-instruction step, four waves per SIMD "
+                                             "(tools/valu_issue_microbench.hip, profiles/r05_valu_issue_microbench.txt)",
+            "simds": 4 * cus, "busy_frac": valu_s / kernel_s}
+    ta = {"busy_cycles_per_step": c["TA_TA_BUSY_sum"], "cu_busy_cycles_per_step": c["SQ_BUSY_CU_CYCLES"],
+          "busy_frac": c["TA_TA_BUSY_sum"] / c["SQ_BUSY_CU_CYCLES"],
+          "vector_memory_instructions_per_step": c.get("SQ_INSTS_VMEM_RD"),
+          "busy_cycles_per_instruction": (c["TA_TA_BUSY_sum"] / c["SQ_INSTS_VMEM_RD"]) if c.get("SQ_INSTS_VMEM_RD") else None}
+    return valu, ta
 
 
 def gather_issue(info, nrows, kernel_s, dev, row_loads_per_tile):
@@ -856,8 +887,11 @@ def main():
         host_tick = run1_host(booster)
     if rank == 0:
         traffic, traffic_src = (None, "not the default single-GPU workload")
+        valu_issue = ta_busy = None
         if world == 1 and use_grid and plain and not args.param:
             traffic, traffic_src = measured_traffic(args.grid, args.kernel, info["num_nodes"])
+            if traffic:
+                valu_issue, ta_busy = unit_busy(kernel_s, dev)
         line = {
             "metric": f"OH gridcells/sec (XGBoost predict), {args.grid.split('L')[0]} L{grid[2]} batch",
             "value": value, "unit": "gridcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -896,7 +930,9 @@ def main():
                          "algorithmic_bytes": algo_bytes,
                          # what actually bounds the walk: gather instructions through the
                          # texture addresser, priced at the 14 cycles a wave64 gather costs at the very least
-                         "gather_issue": gather_issue(info, n_local, kernel_s, dev, 7 if (use_grid or args.consecutive or args.infer_grid or args.no_grid) and not args.shuffle else 9)},
+                         "gather_issue": gather_issue(info, n_local, kernel_s, dev, 7 if (use_grid or args.consecutive or args.infer_grid or args.no_grid) and not args.shuffle else 9),
+                         # (r5) the two units the walk is bound by, from the committed counters of these very kernels
+                         "valu_issue": valu_issue, "ta_busy": ta_busy},
             "cpu_baseline": cpu,
             "pcie_inclusive": pcie,
             "run1_host": host_tick,

@@ -26,6 +26,13 @@ def value(path, name):
     raise SystemExit(f"{name} not in {path}")
 
 
+def opt(path, name):
+    try:
+        return value(path, name)
+    except SystemExit:
+        return None
+
+
 def main():
     pmc, calib, bench = sys.argv[1:4]
     import bench as bench_py
@@ -41,7 +48,12 @@ def main():
         "workload": line["config"]["grid"] and "C360" if line["config"]["grid"] == [360, 2160, 72] else str(line["config"]["grid"]),
         "kernel": "ring", "model_nodes": line["config"]["booster"]["nodes"],
         "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "fetch_calibration": round(scale, 4),
-        "traffic_bytes_per_step": round(traffic), "kernel_source_hash": bench_py.kernel_source_hash(),
+        "traffic_bytes_per_step": round(traffic),
+        # (r5) the counters bench.py's roofline.valu_issue / roofline.ta_busy are made of, same passes, per step
+        "counters_per_step": {name: opt(pmc, name) for name in
+                              ("SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "TA_TA_BUSY_sum", "SQ_BUSY_CU_CYCLES",
+                               "TCP_TOTAL_CACHE_ACCESSES_sum")},
+        "kernel_source_hash": bench_py.kernel_source_hash(),
         "kernel_ms_when_measured": line["roofline"]["kernel_ms"]}, indent=1))
 
 

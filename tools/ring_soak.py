@@ -2,7 +2,7 @@
 """Soak of the ring kernels' barrier-free protocol (measurement aid): the same C360 batch predicted --iters times, the
 launch geometry changed from call to call (rounds per launch, CUs left free, XCD remap, a tree limit now and then), every
 output compared bit for bit with the `wide` kernel's.  A race between the waves of a block would show as a difference
-or as the ring's time-out flag; prints the count of each.  usage (GPU box): python3 tools/ring_soak.py [--iters 600]"""
+or as a time-out (since round 5 a re-run by the tile kernel, counted: OHXBoosterRingReruns); prints the count of each.  usage (GPU box): python3 tools/ring_soak.py [--iters 600]"""
 import argparse
 import os
 import random
@@ -69,7 +69,9 @@ def main():
             print(f"iteration {it}: {bad} rows differ", flush=True)
         if it % 100 == 99:
             print(f"{it + 1} predicts, {wrong} wrong, {errors} errors", flush=True)
-    print(f"ring soak: {args.iters} predicts of {n} rows ({booster.kernel_symbol(27)}), {wrong} with a wrong row, {errors} errors")
+    reruns = booster.ring_reruns()       # (r5) a time-out is no error any more: the rows are predicted again, and counted
+    print(f"ring soak: {args.iters} predicts of {n} rows ({booster.kernel_symbol(27)}), {wrong} with a wrong row, {errors} errors, "
+          f"{reruns} time-outs (re-runs)")
     sys.exit(1 if wrong or errors else 0)
 
 
@@ -119,7 +121,9 @@ def soak_fields(args, grid, n, dev):
             print(f"iteration {it}: {int((out.view(torch.int32) != refs[k1].view(torch.int32)).sum())} gridcells differ", flush=True)
         if it % 100 == 99:
             print(f"{it + 1} fused calls, {wrong} wrong, {errors} errors", flush=True)
-    print(f"ring soak: {args.iters} fused calls on {n} gridcells ({booster.fields_kernel_symbol(n)}), {wrong} with a wrong gridcell, {errors} errors")
+    reruns = booster.ring_reruns()
+    print(f"ring soak: {args.iters} fused calls on {n} gridcells ({booster.fields_kernel_symbol(n)}), {wrong} with a wrong gridcell, "
+          f"{errors} errors, {reruns} time-outs (re-runs)")
     sys.exit(1 if wrong or errors else 0)
 
 
