@@ -609,8 +609,8 @@ void ensure_uploaded(BoosterObj& b) {
     b.d_packed.upload(packed);
   }
   if (pick_kernel(b) == KernelKind::Wide) ensure_wide(b);
-  b.d_flags.ensure(2);      // [0] kFlag* bits, [1] ring re-runs counted on the device (kernels.hip ring_settle_kernel)
-  HIP_CHECK(hipMemset(b.d_flags.p, 0, 2 * sizeof(uint32_t)));
+  b.d_flags.ensure(3);      // [0] kFlag* bits, [1] ring re-runs counted on the device, [2] the train a block last gave up in
+  HIP_CHECK(hipMemset(b.d_flags.p, 0, 3 * sizeof(uint32_t)));
   b.ring_reruns_seen = 0;
   if (!b.train.side) {
     HIP_CHECK(hipStreamCreateWithFlags(&b.train.side, hipStreamNonBlocking));

@@ -17,6 +17,8 @@
 // node loads are in flight per lane, and their leaves are added in tree order.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdint>
 
 #include "kernels.hpp"
@@ -745,10 +747,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
   // noalias: with the margins' stores provably elsewhere, the wave-uniform head records stay scalar
   // loads (as members of the by-value structs they turn into one more vector load per walk)
   extern __shared__ float lds[];
-  // the launch behind a ring train (launch_rows_ring): nothing to do unless a ring block gave up
-  if (a.only_if_flag != 0u &&
-      (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & a.only_if_flag) == 0u)
-    return;
+  // the launch behind a ring train (launch_rows_ring): nothing to do unless a block of that train gave up
+  if (a.only_if_train != 0u) {
+    if (__hip_atomic_load(a.flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.only_if_train) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.flags + 1, 1u);
+  }
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   // the waves' feature tiles first, the first-step table behind them (see tile_lds_bytes)
@@ -910,8 +913,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CHAINS >
 // Every wait is on work with a lower group number, so the waves cannot wait in a circle; the spins are bounded all the
 // same.  A wave that gives up says so in a fourth word, `abort`, which every spinning wave of the block reads: from then
 // on nobody in the block waits, stages, walks or stores - the block runs through its rounds in no time, raises
-// kFlagRingTimeout, and the launch the launcher put behind the train (the tile kernel, predicated on that bit) walks
-// the train's rows instead.  (Until round 4 a time-out was an error: rc -1 into the caller's _ASSERT,
+// the id of its launch train in flags[2], and the launch the launcher put behind the train (the tile kernel, predicated
+// on that id) walks the train's rows instead.  (Until round 4 a time-out was an error: rc -1 into the caller's _ASSERT,
 // OH_GridCompMod.F90:358; and the waves that had not given up themselves spun on, limit after limit.)
 //
 // C360 step: 27.4 ms against the tile kernel's 31.1, and 24.3 with issue priorities (ring_walk_group); with them the ring
@@ -1254,7 +1257,7 @@ __global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4)))
     if (live && keep && !rg.gave_up) __builtin_nontemporal_store(acc, out + this_row);
     tile_id = next;
   }
-  if (rg.gave_up && a.flags) atomicOr(a.flags, kFlagRingTimeout);
+  if (rg.gave_up && a.flags && lane == 0) atomicExch(a.flags + 2, a.train_id);
 }
 
 // The fused path (predict_fields_kernel's fill and store) around the ring walk.
@@ -1310,15 +1313,7 @@ __global__ __launch_bounds__(kRingBlock) __attribute__((amdgpu_waves_per_eu(4)))
     const float acc = ring_walk_tile(rg, fr.base_score, tile, live, wave_nan, lane, wave);
     if (keep && !rg.gave_up) store_oh(a, out, margin_out, slab_out, m, at.at3, acc);
   }
-  if (rg.gave_up && a.flags) atomicOr(a.flags, kFlagRingTimeout);
-}
-
-// Behind a ring train and its predicated tile launch: a time-out is over - the bit goes, the event is counted.
-__global__ void ring_settle_kernel(uint32_t* __restrict__ flags) {
-  if (threadIdx.x == 0 && (flags[0] & kFlagRingTimeout) != 0u) {
-    atomicAnd(flags, ~(uint32_t)kFlagRingTimeout);
-    atomicAdd(flags + 1, 1u);
-  }
+  if (rg.gave_up && a.flags && lane == 0) atomicExch(a.flags + 2, a.train_id);
 }
 
 // The second launch of a small batch (PredictArgs::leaf_buf): one wave per tile, margin = ((base + leaf_0) + leaf_1) + ...
@@ -1381,9 +1376,10 @@ __global__ __launch_bounds__(kBlock) void predict_fields_kernel(DeviceForest fr,
                                                                 float* __restrict__ out,
                                                                 float* __restrict__ margin_out) {
   extern __shared__ float lds[];
-  if (a.only_if_flag != 0u &&       // the launch behind a ring train: nothing to do unless a ring block gave up
-      (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & a.only_if_flag) == 0u)
-    return;
+  if (a.only_if_train != 0u) {      // the launch behind a ring train: nothing to do unless a block of that train gave up
+    if (__hip_atomic_load(a.flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.only_if_train) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.flags + 1, 1u);
+  }
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   float* tile = lds + (size_t)wave * fr.num_feature * kWave + lane;
@@ -2064,6 +2060,14 @@ hipError_t launch_rows_tiled(K kernel, size_t lds, const DeviceForest& fr, Predi
   return hipGetLastError();
 }
 
+// ids of ring launch trains, process-wide, never 0 (PredictArgs::train_id)
+uint32_t next_train_id() {
+  static std::atomic<uint32_t> counter{0};
+  uint32_t id = counter.fetch_add(1, std::memory_order_relaxed) + 1;
+  if (id == 0) id = counter.fetch_add(1, std::memory_order_relaxed) + 1;
+  return id;
+}
+
 // The train of launches of predict_rows_ring_kernel: one 1 024-thread block per CU, `ring_rounds` tiles per wave
 // and launch (the waves of a block walk the same trees by construction; what a launch boundary still buys is that the
 // blocks of an XCD start on tree 0 together).
@@ -2095,6 +2099,7 @@ hipError_t launch_rows_ring(const DeviceForest& fr, PredictArgs a, int num_cus, 
   const int no_grid = a.perm != nullptr ? kRingRoundsPermuted : kRingRoundsNoGrid;
   if (a.shape.im == 0 && (rounds <= 0 || rounds > no_grid)) rounds = no_grid;      // (0 = one launch: for rows on a grid only)
   const uint64_t per_launch = rounds <= 0 ? ntiles : grid * kRingWaves * (uint64_t)rounds;
+  a.train_id = next_train_id();
   TrainCursor train(stream, tune);
   for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
     a.tile_begin = t0;
@@ -2108,17 +2113,17 @@ hipError_t launch_rows_ring(const DeviceForest& fr, PredictArgs a, int num_cus, 
   }
   e = train.meet();
   if (e != hipSuccess) return e;
-  // A ring block that gave up waiting (kFlagRingTimeout) has not written its rows.  Behind the train: the tile kernel
-  // over ALL of the train's rows, every block of which leaves at once unless that bit is set (5 us per step when it
-  // is not), missing-aware and without deferring; then the bit is cleared and the event counted.  Stream-ordered, so
-  // the device forms need no host in the loop (include/ohxgb.h: OHXBoosterGetInfo "ring_reruns").
+  // A ring block that gave up waiting has not written its rows, and says so by writing this train's id to flags[2].
+  // Behind the train: the tile kernel over ALL of the train's rows, every block of which leaves at once unless it finds
+  // that id there (5 us per step when it does not), missing-aware and without deferring; its first block counts the
+  // event.  Stream-ordered, so the device forms need no host in the loop (include/ohxgb.h: OHXBoosterRingReruns).
   if (a.flags != nullptr) {
     auto again = predict_rows_tile_kernel<2, 2, true, true>;
     const size_t lds2 = tile_lds_bytes(fr.num_feature, true);
     e = ensure_lds(again, lds2);
     if (e != hipSuccess) return e;
     PredictArgs b = a;
-    b.only_if_flag = kFlagRingTimeout;
+    b.only_if_train = a.train_id;
     b.defer_list = nullptr;
     b.defer_count = nullptr;
     b.defer_cap = 0;
@@ -2126,7 +2131,6 @@ hipError_t launch_rows_ring(const DeviceForest& fr, PredictArgs a, int num_cus, 
     b.tile_end = ntiles;
     hipLaunchKernelGGL(again, dim3(tile_grid(again, lds2, ntiles, num_cus)), dim3(kBlock), lds2, stream, fr, b, fr.super_heads,
                        b.out);
-    hipLaunchKernelGGL(ring_settle_kernel, dim3(1), dim3(kWave), 0, stream, a.flags);
   }
   return hipGetLastError();
 }
@@ -2318,7 +2322,7 @@ std::string predict_kernel_symbols_rows(KernelKind kind, const DeviceForest& fr,
   if (p.split) return tile(false) + " + combine_leaves_kernel";
   std::string out;
   if (p.ring) {
-    out = "predict_rows_ring_kernel + predict_rows_tile_kernel<2,2,true,true> (only after a ring time-out) + ring_settle_kernel";
+    out = "predict_rows_ring_kernel + predict_rows_tile_kernel<2,2,true,true> (only after a ring time-out)";
     if (p.listing) out += " + predict_rows_tile_kernel<2,2,false,true> (rows with missing values)";
     return out;
   }
@@ -2365,6 +2369,7 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
     if (e != hipSuccess) return e;
   }
   const uint64_t per_launch = rounds <= 0 ? ntiles : (uint64_t)grid * waves_per_block * (uint64_t)rounds;
+  if (ring) a.train_id = next_train_id();
   TrainCursor train(stream, tune);
   for (uint64_t t0 = 0; t0 < ntiles; t0 += per_launch) {
     a.tile_begin = t0;
@@ -2379,13 +2384,13 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
   e = train.meet();
   if (e != hipSuccess) return e;
   if (ring && a.flags != nullptr) {
-    // as launch_rows_ring: the tile kernel over all of the slab, predicated on kFlagRingTimeout, then the settle launch
+    // as launch_rows_ring: the tile kernel over all of the slab, predicated on this train's id in flags[2]
     auto again = predict_fields_kernel<2, 2, true>;
     const size_t lds2 = tile_lds_bytes(fr.num_feature, true);
     e = ensure_lds(again, lds2);
     if (e != hipSuccess) return e;
     FieldsArgs b = a;
-    b.only_if_flag = kFlagRingTimeout;
+    b.only_if_train = a.train_id;
     b.defer_list = nullptr;
     b.defer_count = nullptr;
     b.defer_cap = 0;
@@ -2393,7 +2398,6 @@ hipError_t launch_fields_tiled(K kernel, size_t lds, const DeviceForest& fr, Fie
     b.tile_end = ntiles;
     hipLaunchKernelGGL(again, dim3(tile_grid(again, lds2, ntiles, num_cus)), dim3(kBlock), lds2, stream, fr, b, fr.super_heads,
                        b.out, b.margin_out);
-    hipLaunchKernelGGL(ring_settle_kernel, dim3(1), dim3(kWave), 0, stream, a.flags);
   }
   if (a.defer_list != nullptr && a.defer_cap != 0u) {
     // the second launch: the listed rows, 64 per wave, every lane gathering its own row from the fields

@@ -12,11 +12,8 @@ namespace ohx {
 // Flag bits the kernels raise in a device word
 enum : uint32_t {
   kFlagInfInput = 1u,  // an input value was +-inf while `missing` is finite
-  // ring kernels: a wave gave up waiting for another and its block's results are not written.  Not an error any more:
-  // the launchers put a launch of the tile kernel behind every ring train that only runs when it finds this bit set
-  // (PredictArgs::only_if_flag) and walks the train's rows again, then ring_settle_kernel clears the bit and counts the
-  // event in the word after the flags (flags[1]; OHXBoosterGetInfo "ring_reruns")
-  kFlagRingTimeout = 2u,
+  // (2u was the ring kernels' time-out until round 4, an error.  A time-out is now recorded as the id of its launch
+  // train in the third word of the flags buffer - flags[2] - and settled on the stream: PredictArgs::train_id.)
 };
 
 // trees whose first-step super-nodes the tile kernels keep in LDS (kernels.hip)
@@ -117,8 +114,13 @@ struct PredictArgs {
   uint32_t tree_begin = 0, tree_end = 0;
   float* out = nullptr;         // [nrow] margins, or [nrow][ntree] leaf ids when pred_leaf
   bool pred_leaf = false;
-  uint32_t* flags = nullptr;    // two device words: [0] OR-ed with kFlag*, [1] ring re-runs counted by ring_settle_kernel
-  uint32_t only_if_flag = 0;    // tile kernels: not 0 = every block leaves at once unless flags[0] holds one of these bits
+  // three device words: [0] OR-ed with kFlag*; [1] ring re-runs (counted by the launch that re-runs); [2] the id of the
+  // last ring launch train in which a block gave up waiting for another and left its rows unwritten
+  uint32_t* flags = nullptr;
+  // ring kernels: the id of this launch train (never 0), written to flags[2] by a block that gives up.  Tile kernels: not
+  // 0 = this is the launch the launchers put behind train `only_if_train`: every block leaves at once unless flags[2]
+  // holds that id - then the launch predicts the train's rows again (and block 0 counts it in flags[1])
+  uint32_t train_id = 0, only_if_train = 0;
   uint64_t tile_begin = 0;      // first 64-row tile of this launch (tile kernels)
   uint64_t tile_end = 0;        // one past the last tile of this launch
   int xcd_remap = 1;            // give each XCD a contiguous range of tiles
@@ -232,7 +234,7 @@ struct FieldsArgs {
   float* out = nullptr;        // (im,jm,km) array; only levels k1..k2 are written
   float* margin_out = nullptr; // optional [N] raw margins in slab row order
   uint32_t* flags = nullptr;   // as PredictArgs::flags
-  uint32_t only_if_flag = 0;   // as PredictArgs::only_if_flag
+  uint32_t train_id = 0, only_if_train = 0;      // as PredictArgs
   uint64_t tile_begin = 0, tile_end = 0;   // 64-row tiles of this launch
   int xcd_remap = 1;           // give each XCD a contiguous range of tiles
   TileShape shape;             // lanes -> gridcells of the slab

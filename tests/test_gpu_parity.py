@@ -855,8 +855,8 @@ def test_a_ring_time_out_is_predicted_again_not_raised(torch_cuda, deep_model, c
     """a ring block that gives up waiting used to end in rc -1 ("error flags 2") and the caller's
     _ASSERT(rc==0) (OH_GridCompMod.F90:356-358).  A scratch build whose waves give up after ONE look (tools/build_variant.sh
     ringspin1 -DOHX_EXP_RING_SPIN=1, made by __graft_entry__.build()) times out in nearly every block: the launch behind
-    the train - the tile kernel, which only runs when the time-out bit is set - predicts the rows again, the bit is
-    cleared, the event counted.  Margins bit for bit against the oracle: the host form, the device form without
+    the train - the tile kernel, which only runs when that train's id stands in the time-out word - predicts the rows again
+    and counts the event.  Margins bit for bit against the oracle: the host form, the device form without
     OHXBoosterCheck, with and without missing values, and the fused fields call."""
     if not os.path.exists(RING_SPIN1):
         pytest.skip("tools/bin/variants/ringspin1 not built")

@@ -237,3 +237,25 @@ def test_product_shell_on_the_gpu_against_the_reference_child(tmp_path, small_mo
     out, *_ = run_both(tmp_path, small_model, REF_ORACLE, tg.DRIVER_HIP, **kw)
     (ref, _), (prod, _) = out["reference"], out["product"]
     assert compare(ref, prod, tolerance=POW10) == boosts
+
+
+@pytest.mark.gpu
+def test_reference_child_and_product_shell_on_a_block_the_ring_kernels_take(tmp_path, deep_model):
+    """The same comparison at a size where the big-batch kernels do the work: a 96 x 72 x 72 block (497 664 gridcells; the
+    slab ~350 000 rows), the OH booster's shape (100 trees of depth 18).  The reference's child reaches the MI355X through
+    XGDMatrixCreateFromMat / XGBoosterPredict (predict_rows_ring_kernel behind the level-size search), the product's shell
+    through OHXBoosterRun1 (feature kernels, slab count, fused walk); one Boost tick and one that skips it."""
+    grid = (96, 72, 72)
+    kw = dict(grid=grid, source="ONLINE_INST", nticks=3, seed=5, once_per_day=True, spinup=False, run_dt=1800, oh_dt=1800,
+              avg24_tick=-1, ohscale=0.85, ref_time="003000", beg="20240131 000000")
+    cpu_and_gpu, *_ = run_both(tmp_path, deep_model, REF_ORACLE, REF_HIP, **kw)
+    (cpu, _), (gpu, _) = cpu_and_gpu["reference"], cpu_and_gpu["product"]
+    for a, b in zip(cpu, gpu):                   # the reference's child: GPU against oracle, every field, bit for bit
+        for name in ["OH"] + [e for e, _ in EXPORTS]:
+            assert np.array_equal(helpers.bits(a["OH"][name]), helpers.bits(b["OH"][name])), (a["tick"], name)
+    other = tmp_path / "shell"
+    other.mkdir()
+    out, *_ = run_both(other, deep_model, REF_HIP, tg.DRIVER_HIP, **kw)
+    (ref, _), (prod, _) = out["reference"], out["product"]
+    assert compare(ref, prod, tolerance=POW10) == 1
+    assert np.count_nonzero(prod[0]["OH"]["OH_boost"]) > 200_000
