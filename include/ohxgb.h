@@ -117,6 +117,9 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *                     cannot check - ROCm's follows the process's page tables, so the next copy faults rather than
  *                     reads stale pages, but it fails.  Nothing is unregistered under a copy in flight (the device
  *                     is synchronised first).  Default 0 (the OH shell turns it on: register_host_arrays, default T)
+ *   "ohx_copy_blocks" process-wide: blocks per launch of the kernel that moves registered host arrays (default 64; 0 = a
+ *                     block per KiB).  Small on purpose: a chip full of wavefronts waiting on PCIe moves a rank's arrays
+ *                     slower and keeps every other stream's kernels from starting meanwhile
  *   "ohx_tree_tops"   auto | on | off : super-nodes: fetch a tree's first records with one coalesced load per
  *                     wavefront (auto = forests of 7 or more steps per tree, where it is faster)
  *   "ohx_cluster"     auto | on | off : group rows of no known order by the decisions they take at the top of
@@ -229,7 +232,17 @@ int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fie
  * All arrays are Fortran order: 3-D (im,jm,km), edge fields (im,jm,0:km), 2-D
  * (im,jm).  MAPL's constants are passed in, not restated.  Host form stages
  * through HBM and returns when the outputs are complete; device form takes device
- * pointers and enqueues (it synchronises the stream once, to read the slab). */
+ * pointers and enqueues (it waits once, for the slab count, which runs on a stream of
+ * the booster's own beside the feature kernels).
+ * Host form: the arrays cross PCIe in the order the tick needs them - PLE and TROPP of
+ * the model (the slab count), the feature engineering's inputs, then what only the walk
+ * reads (of the sixteen 3-D fields among those, the slab's levels only), last and under
+ * the walk what the mask and the unit conversion read.  The same array may be passed
+ * for several members (ONLINE_INST: T is t_mod and t_bst): it crosses once.  With
+ * "ohx_register_host" every list is one launch of a small copy kernel.  OHX_RUN1_STREAMS
+ * = 1 | 2 | 3 in the environment (read once; default 3) limits the streams a host-form
+ * tick uses - for a node that runs so many ranks per GPU that their queues outnumber the
+ * hardware's (GPU_MAX_HW_QUEUES does the same from outside). */
 typedef struct OHXRun1Args {
   int32_t im, jm, km;
   int32_t dynamic_k_range;           /* .NOT. compute_once_per_day (:1561) */

@@ -15,6 +15,7 @@
 #include <fstream>
 #include <memory>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <unordered_map>
 #include <sstream>
@@ -1541,6 +1542,27 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
 // The host form's side of a tick (OHXBoosterRun1): its arrays cross PCIe in three lists on a copy stream, and
 // run1_device says when - what the slab count needs first, what the feature engineering needs behind it, and the
 // rest once the slab is known (of the sixteen fields only the walk reads, the slab's levels alone).
+// Where the HOST spends a host-form tick (OHX_RUN1_TRACE=1 in the environment; measurement aid): microseconds since the
+// call began at a few marks, printed for ticks 50 .. 52 of the process.
+struct TickTrace {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  std::vector<std::pair<const char*, double>> marks;
+  void mark(const char* what) {
+    marks.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+  void print(unsigned tick) const {
+    std::string line = "[libohxgb] run1 tick " + std::to_string(tick) + " (host, us):";
+    char buf[96];
+    for (const auto& m : marks) {
+      snprintf(buf, sizeof buf, " %s %.1f", m.first, m.second);
+      line += buf;
+    }
+    fprintf(stderr, "%s\n", line.c_str());
+  }
+};
+thread_local TickTrace* g_tick_trace = nullptr;
+#define TICK_MARK(what) do { if (g_tick_trace) g_tick_trace->mark(what); } while (0)
+
 struct Run1Feed {
   virtual ~Run1Feed() = default;
   // each enqueues copies on the feed's own stream and returns an event recorded behind them
@@ -1682,7 +1704,9 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   }
   // the one wait in the middle of a tick: the slab count sizes the walk's launches (and the reference asserts on it,
   // :287-288); it was enqueued before everything else of this tick and the features are being computed meanwhile
+  TICK_MARK("features-enqueued");
   HIP_CHECK(hipEventSynchronize(b.run1_slab));
+  TICK_MARK("slab-known");
   const int32_t slab[2] = {b.h_slab.p[0], b.h_slab.p[1]};
   if (!r.dynamic_k_range && slab[1] != 0) {
     (void)hipStreamSynchronize(side);
@@ -1694,6 +1718,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   if (r.k2) *r.k2 = k2;
   hipEvent_t post_inputs = nullptr;
   if (feed != nullptr) HIP_CHECK(hipStreamWaitEvent(stream, feed->walk_inputs(k1, k2), 0));
+  TICK_MARK("walk-inputs-enqueued");
 
   const float* fields[27] = {r.lat_deg, pl_bst, r.t_bst, r.no2, r.o3, r.ch4, r.co, r.isop, r.acet, r.c2h6, r.c3h8,
                              r.prpe, r.alk4, r.mp, r.h2o2, tauclwdn, tauclidn, taucliup, tauclwup, r.cloud, r.qv,
@@ -1732,6 +1757,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
       HIP_CHECK(launch_predict_fields(kind, device_forest(b), fa, b.dev.num_cus, stream, tune));
       if (deferring && q + 1 == npieces) defer_look(b, slab_rows, stream);
     }
+    TICK_MARK("walk-enqueued");
     if (feed != nullptr && post_inputs == nullptr) post_inputs = feed->post_inputs();      // behind the (first) walk's launch
     if (npieces == 1) {
       if (post_inputs != nullptr) HIP_CHECK(hipStreamWaitEvent(stream, post_inputs, 0));
@@ -2033,12 +2059,19 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   }
   static const int nstreams = [] { const char* e = getenv("OHX_RUN1_STREAMS"); return e ? atoi(e) : 3; }();
   hipStream_t main = nstreams == 1 ? b->s_copy : b->s_exec;
+  static const bool tracing = getenv("OHX_RUN1_TRACE") != nullptr;
+  static std::atomic<unsigned> tick_no{0};
+  TickTrace trace;
+  const unsigned tick = tick_no.fetch_add(1);
+  g_tick_trace = (tracing && tick >= 50 && tick <= 52) ? &trace : nullptr;
+  TICK_MARK("set-up");
   try {
     run1_device(*b, d, main, &feed);
   } catch (...) {
     // nothing of this call may still be reading the caller's arrays when it returns, error or not
     (void)hipStreamSynchronize(b->s_copy);
     (void)hipStreamSynchronize(main);
+    g_tick_trace = nullptr;
     throw;
   }
   HostMover back(main, false);
@@ -2048,7 +2081,11 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   for (size_t i = 0; i < nout; ++i)
     if (outs[i].host) back.add(outs[i].host, *outs[i].dev, outs[i].n);
   back.go();
+  TICK_MARK("all-enqueued");
   raise_flag_errors(*b, main);          // waits for the stream: the outputs are in the caller's arrays
+  TICK_MARK("done");
+  if (g_tick_trace) g_tick_trace->print(tick);
+  g_tick_trace = nullptr;
   API_END();
 }
 
