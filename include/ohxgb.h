@@ -232,17 +232,22 @@ int OHXBoosterPredictFieldsDevice(BoosterHandle handle, const float* const d_fie
  * All arrays are Fortran order: 3-D (im,jm,km), edge fields (im,jm,0:km), 2-D
  * (im,jm).  MAPL's constants are passed in, not restated.  Host form stages
  * through HBM and returns when the outputs are complete; device form takes device
- * pointers and enqueues (it waits once, for the slab count, which runs on a stream of
- * the booster's own beside the feature kernels).
+ * pointers and enqueues (it waits once, for the slab count, which runs on the
+ * library's second stream beside the feature kernels).
  * Host form: the arrays cross PCIe in the order the tick needs them - PLE and TROPP of
  * the model (the slab count), the feature engineering's inputs, then what only the walk
  * reads (of the sixteen 3-D fields among those, the slab's levels only), last and under
  * the walk what the mask and the unit conversion read.  The same array may be passed
  * for several members (ONLINE_INST: T is t_mod and t_bst): it crosses once.  With
- * "ohx_register_host" every list is one launch of a small copy kernel.  OHX_RUN1_STREAMS
- * = 1 | 2 | 3 in the environment (read once; default 3) limits the streams a host-form
- * tick uses - for a node that runs so many ranks per GPU that their queues outnumber the
- * hardware's (GPU_MAX_HW_QUEUES does the same from outside). */
+ * "ohx_register_host" every list is one launch of a small copy kernel.
+ * Streams: the library owns two per device for the life of the process - one for kernels, one
+ * for copies - and nothing of it runs on the null stream; every stream a process has used
+ * is a hardware queue, and a GPU that several ranks share time-slices queues once they
+ * outnumber its slots.  Experiment knobs in the environment, read
+ * once: OHX_RUN1_STREAMS=1 (copies on the kernels' stream), OHX_RUN1_GATE=1 (a kernel
+ * is launched when this thread has seen its inputs arrive, not enqueued behind a wait for
+ * them), OHX_RUN1_SLAB_IN_PLACE=1 (the slab count reads the caller's registered PLE and
+ * TROPP over PCIe); both measured worth nothing, both off. */
 typedef struct OHXRun1Args {
   int32_t im, jm, km;
   int32_t dynamic_k_range;           /* .NOT. compute_once_per_day (:1561) */

@@ -117,6 +117,37 @@ DeviceInfo use_device(int ordinal) {
   return d;
 }
 
+// The two streams everything of this library runs on (per device, made at first use, kept for the life of the process):
+// `exec` for kernels and whatever must stay in order with them, `copy` for PCIe transfers that run beside them.  None of
+// the library's own work goes to the null stream, and no object has streams of its own: every stream a process has ever
+// used is a hardware queue the GPU's scheduler keeps mapped, and a GPU shared by several MPI ranks - how GEOS runs -
+// time-slices queues once there are more of them than it has slots.  Six ranks with four queues each: a tick in a
+// hundred took 14-37 ms instead of 1; with two each, none did (profiles/r05_sweeps.txt, "six ranks").
+struct LibStreams {
+  hipStream_t exec = nullptr, copy = nullptr;
+};
+LibStreams& lib_streams(int ordinal) {
+  static std::mutex mu;
+  static std::unordered_map<int, LibStreams> by_device;
+  std::lock_guard<std::mutex> g(mu);
+  LibStreams& ls = by_device[ordinal];
+  if (ls.exec == nullptr) {
+    int cur = 0;
+    HIP_CHECK(hipGetDevice(&cur));
+    if (cur != ordinal) HIP_CHECK(hipSetDevice(ordinal));
+    HIP_CHECK(hipStreamCreateWithFlags(&ls.exec, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&ls.copy, hipStreamNonBlocking));
+    if (cur != ordinal) HIP_CHECK(hipSetDevice(cur));
+  }
+  return ls;
+}
+// the current device's
+hipStream_t exec_stream() {
+  int cur = 0;
+  HIP_CHECK(hipGetDevice(&cur));
+  return lib_streams(cur).exec;
+}
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -135,7 +166,10 @@ struct DevBuf {
   }
   void upload(const std::vector<T>& h) {
     ensure(h.size());
-    if (!h.empty()) HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (h.empty()) return;
+    hipStream_t s = exec_stream();
+    HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));      // `h` is the caller's again
   }
 };
 
@@ -361,6 +395,16 @@ struct HostMover {
     HIP_CHECK(hipMemcpyAsync(to_device ? (void*)dev : (void*)host, to_device ? (const void*)host : (const void*)dev,
                              count * sizeof(float), to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, stream));
   }
+  // a few words between HBM and pinned memory of the library's own (hipHostMalloc: the GPU reaches it at its host address),
+  // riding on the list's launch; false when the list is full or empty - the caller copies them its own way then
+  bool ride(void* dst, const void* src, size_t words) {
+    if (list.count == 0 || list.count >= kCopyListMax) return false;
+    list.src[list.count] = static_cast<const float*>(src);
+    list.dst[list.count] = static_cast<float*>(dst);
+    list.n[list.count] = words;
+    ++list.count;
+    return true;
+  }
   void go() {
     HIP_CHECK(launch_copy_arrays(list, stream, g_copy_blocks.load(std::memory_order_relaxed)));
     list.count = 0;
@@ -427,9 +471,6 @@ struct DMatrixObj {
 
 struct BoosterObj {
   ~BoosterObj() {
-    if (s_copy) (void)hipStreamDestroy(s_copy);
-    if (s_exec) (void)hipStreamDestroy(s_exec);
-    if (s_run1) (void)hipStreamDestroy(s_run1);
     for (hipEvent_t e : {run1_fork, run1_slab, run1_join})
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : run1_prep) (void)hipEventDestroy(e);
@@ -441,7 +482,7 @@ struct BoosterObj {
     if (cluster_done) (void)hipEventDestroy(cluster_done);
     if (defer_seen) (void)hipEventDestroy(defer_seen);
   }
-  TrainStreams train;              // second stream of the launch train (kernels.hpp), made at upload
+  TrainStreams train;              // second stream of the launch train (kernels.hpp): made when ohx_overlap_group asks for it
   Forest forest;
   bool loaded = false;
   float margin_base = 0.0f;        // Forest::margin_base() of the loaded model
@@ -472,16 +513,17 @@ struct BoosterObj {
   DevBuf<uint32_t> d_defer;             // deferred rows (kernels.hpp PredictArgs::defer_list): the count, then the list
   // how many rows of the last batch held missing values (read back behind the batch, looked at before the next one)
   PinnedBuf<uint32_t> h_defer_count;
+  PinnedBuf<uint32_t> h_flags;          // d_flags[0..1] as the last copy-back kernel of a host-form tick left them
   hipEvent_t defer_seen = nullptr;
   bool defer_pending = false;
   uint64_t defer_last_nrow = 0;
   bool defer_too_many = false;
   DevBuf<float> d_pred;
   PinnedBuf<float> h_pred;
-  hipStream_t s_copy = nullptr, s_exec = nullptr;   // fused host path: PCIe copies beside the kernels
-  // OH Run1 (run1_device): the slab count, and the streaming kernels of the pieces that are not being walked, run on a
-  // side stream beside the caller's
-  hipStream_t s_run1 = nullptr;
+  // the library's two streams on the booster's device (lib_streams; not the booster's to destroy).  Host forms of the
+  // fused calls: PCIe copies on s_copy beside the kernels on s_exec.  OH Run1's device form: the slab count, and the
+  // streaming kernels of the pieces that are not being walked, on s_copy beside the caller's stream
+  hipStream_t s_copy = nullptr, s_exec = nullptr;
   hipEvent_t run1_fork = nullptr, run1_slab = nullptr, run1_join = nullptr;
   std::vector<hipEvent_t> run1_prep, run1_walk, run1_feed_events;
   PinnedBuf<int32_t> h_slab;
@@ -490,6 +532,7 @@ struct BoosterObj {
   // Run1: engineered features, OH_ML and the slab result stay in HBM between the steps
   DevBuf<float> d_run1[10];
   DevBuf<int32_t> d_slab;
+  bool slab_zeroed = false;            // d_slab's two words are zero whenever no slab count is enqueued (run1_device)
   // clustering pass for rows in no known order (kernels.hip)
   DevBuf<uint32_t> d_cluster_keys[2], d_cluster_vals[2], d_cluster_small;
   DevBuf<uint8_t> d_cluster_temp;
@@ -582,6 +625,8 @@ void ensure_wide(BoosterObj& b) {
   b.d_wide.upload(wide);
 }
 
+void ensure_train_stream(BoosterObj& b);
+
 void ensure_uploaded(BoosterObj& b) {
   if (!b.loaded) throw OhxError("the booster holds no model: call XGBoosterLoadModel first");
   if (b.uploaded) {
@@ -611,15 +656,29 @@ void ensure_uploaded(BoosterObj& b) {
   }
   if (pick_kernel(b) == KernelKind::Wide) ensure_wide(b);
   b.d_flags.ensure(3);      // [0] kFlag* bits, [1] ring re-runs counted on the device, [2] the train a block last gave up in
-  HIP_CHECK(hipMemset(b.d_flags.p, 0, 3 * sizeof(uint32_t)));
+  {
+    LibStreams& ls = lib_streams(b.dev.ordinal);
+    b.s_exec = ls.exec;
+    b.s_copy = ls.copy;
+  }
+  HIP_CHECK(hipMemsetAsync(b.d_flags.p, 0, 3 * sizeof(uint32_t), b.s_exec));
+  HIP_CHECK(hipStreamSynchronize(b.s_exec));
   b.ring_reruns_seen = 0;
+  ensure_train_stream(b);
+  b.uploaded = true;
+}
+
+// the launch train's second stream exists only for a booster that was told to use it (ohx_overlap_group >= 2: an
+// experiment knob): a stream is a hardware queue for the life of the process (LibStreams)
+void ensure_train_stream(BoosterObj& b) {
+  b.tune.train = nullptr;
+  if (b.tune.overlap_group < 2) return;
   if (!b.train.side) {
     HIP_CHECK(hipStreamCreateWithFlags(&b.train.side, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&b.train.fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&b.train.join, hipEventDisableTiming));
   }
   b.tune.train = &b.train;
-  b.uploaded = true;
 }
 
 DeviceForest device_forest(const BoosterObj& b) {
@@ -668,10 +727,17 @@ void check_columns(const BoosterObj& b, uint64_t ncol) {
                    " vs. " + std::to_string(b.forest.num_feature) + ")");
 }
 
+void judge_flags(BoosterObj& b, const uint32_t flags[2], hipStream_t stream);
+
 void raise_flag_errors(BoosterObj& b, hipStream_t stream) {
   uint32_t flags[2] = {0, 0};
   HIP_CHECK(hipMemcpyAsync(flags, b.d_flags.p, sizeof(flags), hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
+  judge_flags(b, flags, stream);
+}
+
+// `flags` = the first two words of d_flags as read back behind the work on `stream`, which the caller has waited for
+void judge_flags(BoosterObj& b, const uint32_t flags[2], hipStream_t stream) {
   // a ring block that timed out is not an error: its rows were walked again by the tile kernel on the stream, behind
   // the train (kernels.hip launch_rows_ring); worth a line on stderr the first time, and a counter from then on
   if (flags[1] != b.ring_reruns_seen) {
@@ -1003,14 +1069,16 @@ int XGDMatrixCreateFromMat(const float* data, bst_ulong nrow, bst_ulong ncol, fl
   d->d_data = d->owned;
   if (count) {
     // two waits per call: the copy itself (pageable host memory) and one read-back of the inf flag
-    HIP_CHECK(hipMemcpy(d->owned, data, count * sizeof(float), hipMemcpyHostToDevice));
+    hipStream_t s = lib_streams(dev.ordinal).exec;
+    HIP_CHECK(hipMemcpyAsync(d->owned, data, count * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));          // `data` is the caller's again (:383 deallocates it)
     // xgboost 1.6.0 (SparsePage::Push): "Input data contains `inf` or `nan`"
     std::lock_guard<std::mutex> g(g_check.mu);
     g_check.ensure(1, dev.ordinal);
-    HIP_CHECK(hipMemsetAsync(g_check.d.p, 0, sizeof(uint32_t), nullptr));
-    HIP_CHECK(launch_scan_dense(d->owned, count, missing, g_check.d.p, nullptr));
-    HIP_CHECK(hipMemcpyAsync(g_check.h.p, g_check.d.p, sizeof(uint32_t), hipMemcpyDeviceToHost, nullptr));
-    HIP_CHECK(hipStreamSynchronize(nullptr));
+    HIP_CHECK(hipMemsetAsync(g_check.d.p, 0, sizeof(uint32_t), s));
+    HIP_CHECK(launch_scan_dense(d->owned, count, missing, g_check.d.p, s));
+    HIP_CHECK(hipMemcpyAsync(g_check.h.p, g_check.d.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
     if (g_check.h.p[0] & kFlagInfInput) throw OhxError("Input data contains `inf` or `nan`");
   }
   g_dmats.add(d.get());
@@ -1024,7 +1092,7 @@ int OHXDMatrixGetGrid(DMatrixHandle handle, int* im, int* jm, bst_ulong* row0, i
   // a matrix the library copied itself can be searched whenever it is asked about
   if (d->owned != nullptr && !d->grid_looked && d->grid_im == 0) {
     HIP_CHECK(hipSetDevice(d->device));
-    infer_level_size(*d, nullptr);
+    infer_level_size(*d, lib_streams(d->device).exec);
   }
   if (im) *im = d->grid_im;
   if (jm) *jm = d->grid_jm;
@@ -1105,7 +1173,9 @@ int XGDMatrixSaveBinary(DMatrixHandle handle, const char* fname, int silent) {
   std::vector<float> host(count);
   if (count) {
     HIP_CHECK(hipSetDevice(d->device));
-    HIP_CHECK(hipMemcpy(host.data(), d->d_data, count * sizeof(float), hipMemcpyDeviceToHost));
+    hipStream_t st = lib_streams(d->device).exec;
+    HIP_CHECK(hipMemcpyAsync(host.data(), d->d_data, count * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
   }
   std::ofstream o(fname, std::ios::binary);
   if (!o) throw OhxError(std::string("cannot open '") + fname + "' for writing");
@@ -1323,6 +1393,10 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     const int k = atoi(value);
     if (k < 0) throw OhxError("ohx_overlap_group must be >= 0");
     b->tune.overlap_group = k;
+    if (b->uploaded) {
+      HIP_CHECK(hipSetDevice(b->dev.ordinal));
+      ensure_train_stream(*b);
+    }
   } else if (n == "ohx_tree_tops") {
     const std::string v = value;
     if (v != "auto" && v != "on" && v != "off") throw OhxError("ohx_tree_tops must be auto, on or off");
@@ -1351,9 +1425,9 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
   ensure_uploaded(*b);
   b->d_pred.ensure(count);
   b->h_pred.ensure(count);
-  launch_predict_checked(*b, *d, option_mask, ntree_limit, b->d_pred.p, nullptr);
-  if (count) HIP_CHECK(hipMemcpy(b->h_pred.p, b->d_pred.p, count * sizeof(float), hipMemcpyDeviceToHost));
-  raise_flag_errors(*b, nullptr);
+  launch_predict_checked(*b, *d, option_mask, ntree_limit, b->d_pred.p, b->s_exec);
+  if (count) HIP_CHECK(hipMemcpyAsync(b->h_pred.p, b->d_pred.p, count * sizeof(float), hipMemcpyDeviceToHost, b->s_exec));
+  raise_flag_errors(*b, b->s_exec);              // waits for the stream: the predictions are in h_pred
   *out_len = count;
   *out_result = b->h_pred.p;
   API_END();
@@ -1452,10 +1526,6 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
   // levels: while piece c is being walked on the compute stream, piece c+1 is already on its
   // way over PCIe on the copy stream (a step is PCIe-bound: 756 MB in, 28 MB out for a
   // C360/8 sub-domain, against ~6 ms of kernels).
-  if (b->s_copy == nullptr) {
-    HIP_CHECK(hipStreamCreateWithFlags(&b->s_copy, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&b->s_exec, hipStreamNonBlocking));
-  }
   // pieces of at least two residencies of rows (the launch granule), at most 8 pieces
   const size_t min_rows = (size_t)64 * 256 * 20 * 2;
   size_t lev_per_piece = (min_rows + plane - 1) / plane;
@@ -1501,11 +1571,13 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
       HIP_CHECK(hipMemcpyAsync(b->d_stage[(size_t)f].p + plane * l0, src, plane * (l1 - l0) * sizeof(float),
                                hipMemcpyHostToDevice, b->s_copy));
     }
-    hipEvent_t ev;
-    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    events.push_back(ev);
-    HIP_CHECK(hipEventRecord(ev, b->s_copy));
-    HIP_CHECK(hipStreamWaitEvent(b->s_exec, ev, 0));
+    if (!one_launch) {           // (one launch: the list went to the kernels' own stream, in front of them)
+      hipEvent_t ev;
+      HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      events.push_back(ev);
+      HIP_CHECK(hipEventRecord(ev, b->s_copy));
+      HIP_CHECK(hipStreamWaitEvent(b->s_exec, ev, 0));
+    }
     FieldsArgs piece = a;
     piece.k1 = a.k1 + (int)l0;
     piece.k2 = a.k1 + (int)l1 - 1;
@@ -1544,6 +1616,7 @@ int OHXBoosterPredictFields(BoosterHandle handle, const float* const fields[], c
 // rest once the slab is known (of the sixteen fields only the walk reads, the slab's levels alone).
 // Where the HOST spends a host-form tick (OHX_RUN1_TRACE=1 in the environment; measurement aid): microseconds since the
 // call began at a few marks, printed for ticks 50 .. 52 of the process.
+namespace {
 struct TickTrace {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   std::vector<std::pair<const char*, double>> marks;
@@ -1560,7 +1633,7 @@ struct TickTrace {
     fprintf(stderr, "%s\n", line.c_str());
   }
 };
-thread_local TickTrace* g_tick_trace = nullptr;
+static thread_local TickTrace* g_tick_trace = nullptr;
 #define TICK_MARK(what) do { if (g_tick_trace) g_tick_trace->mark(what); } while (0)
 
 struct Run1Feed {
@@ -1570,7 +1643,15 @@ struct Run1Feed {
   virtual hipEvent_t prep_inputs() = 0;                              // what the feature engineering reads
   virtual hipEvent_t walk_inputs(int k1, int k2) = 0;                // 1-based slab levels
   virtual hipEvent_t post_inputs() = 0;                              // what the tick's last kernel reads; asked for once the walk is enqueued
+  // true when the slab count may read PLE and TROPP where the caller has them (registered arrays: *ple, *tropp = the
+  // addresses the GPU reaches them at): it then waits for nothing, and their device copies - the tick's last kernel
+  // reads them too - cross with prep_inputs(); slab_inputs() is not called
+  virtual bool slab_in_place(const float** ple, const float** tropp) { (void)ple; (void)tropp; return false; }
+  // true: a kernel that needs a list is launched when the HOST has seen the list's event, not enqueued behind a wait
+  // on it (run1_device, below)
+  virtual bool host_gated() const { return false; }
 };
+}  // namespace
 
 static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream, Run1Feed* feed = nullptr) {
   if (r.im <= 0 || r.jm <= 0 || r.km <= 0) throw OhxError("OHXBoosterRun1: im, jm, km must be positive");
@@ -1607,40 +1688,57 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   // C360 tick's 20.2 when they ran one after the other around the walk) only the first piece's features and the last
   // piece's post-processing are not hidden behind a walk, which leaves the CUs' spare registers and the whole of HBM's
   // bandwidth to them.  A slab of fewer than two launches of the ring kernel (a rank's block) is one piece.
-  if (!b.s_run1) {
-    HIP_CHECK(hipStreamCreateWithFlags(&b.s_run1, hipStreamNonBlocking));
+  if (!b.run1_fork) {
     HIP_CHECK(hipEventCreateWithFlags(&b.run1_fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&b.run1_slab, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&b.run1_join, hipEventDisableTiming));
   }
   b.h_slab.ensure(2);
-  // the host form of a rank's block may be told to use fewer queues (experiment knob OHX_RUN1_STREAMS=1|2|3, read once):
-  // many ranks share a GPU, and every stream of every process is a hardware queue the scheduler has to map
-  static const int nstreams = [] { const char* e = getenv("OHX_RUN1_STREAMS"); return e ? atoi(e) : 3; }();
-  hipStream_t side = (feed != nullptr && nstreams < 3) ? stream : b.s_run1;
-  HIP_CHECK(hipEventRecord(b.run1_fork, stream));            // the side stream starts behind what the caller has enqueued
-  HIP_CHECK(hipStreamWaitEvent(side, b.run1_fork, 0));
-  // host form: PLE and TROPP cross first, and the slab count is enqueued behind them before anything else is even
-  // listed - its answer is back on the host while the features' inputs are still crossing, so the walk's own inputs
-  // follow them over PCIe without a gap
-  hipEvent_t prep_inputs = nullptr;
-  if (feed != nullptr) {
-    HIP_CHECK(hipStreamWaitEvent(side, feed->slab_inputs(), 0));
-    // ... and the next list is handed to the copy stream before this thread turns to anything else: the six calls that
-    // enqueue the slab count took it 50 us, during which the link stood idle (profiles/r05_sweeps.txt)
-    prep_inputs = feed->prep_inputs();
+  // The side stream.  Device form: the library's copy stream, idle there (the slab count runs beside the first
+  // features: 0.19 ms of a C360 tick).  Host form: the copy stream carries the copies, and the side work goes to the
+  // caller's stream in order - a third stream made a rank's tick slower alone (0.36-0.41 against 0.32 ms) and gave six
+  // ranks on one GPU more queues than its scheduler maps at once (LibStreams; profiles/r05_sweeps.txt)
+  hipStream_t side = (feed != nullptr || stream == b.s_copy) ? stream : b.s_copy;
+  if (side != stream) {
+    HIP_CHECK(hipEventRecord(b.run1_fork, stream));          // the side stream starts behind what the caller has enqueued
+    HIP_CHECK(hipStreamWaitEvent(side, b.run1_fork, 0));
   }
-
+  // host form: the slab count is the first thing of the tick.  Registered arrays: it reads PLE and TROPP over PCIe where
+  // they are (0.34 MB of a rank's block; every edge once) and waits for no copy.  Else they cross first and it follows
+  // them.  Either way its answer is back on the host while the features' inputs are still crossing, so the walk's own
+  // inputs follow those over PCIe without a gap.
   SlabArgs sa;
   sa.im = r.im; sa.jm = r.jm; sa.km = r.km;
   sa.dynamic_k_range = r.dynamic_k_range; sa.tropp_min = r.tropp_min;
   sa.ple_mod = r.ple_mod; sa.tropp = r.tropp_mod; sa.result = b.d_slab.p;
-  HIP_CHECK(hipMemsetAsync(b.d_slab.p, 0, 2 * sizeof(int32_t), side));
+  hipEvent_t prep_inputs = nullptr;
+  const bool gated = feed != nullptr && feed->host_gated() && b.tune.run1_pieces <= 1;
+  if (feed != nullptr) {
+    if (!feed->slab_in_place(&sa.ple_mod, &sa.tropp)) {
+      hipEvent_t ev = feed->slab_inputs();
+      if (gated) HIP_CHECK(hipEventSynchronize(ev)); else HIP_CHECK(hipStreamWaitEvent(side, ev, 0));
+    }
+  }
+  // (the result words are zero: set so when they were made, and again behind every read-back - a memset in front of the
+  // count was a 12 us launch on the tick's critical path)
+  if (!b.slab_zeroed) {
+    HIP_CHECK(hipMemsetAsync(b.d_slab.p, 0, 2 * sizeof(int32_t), side));
+    b.slab_zeroed = true;
+  }
   HIP_CHECK(launch_k_slab(sa, side));
+  // ... and the next list is handed to the copy stream before this thread turns to anything else: the calls that
+  // enqueue the rest of the slab count took it 50 us, during which the link stood idle (profiles/r05_sweeps.txt)
+  if (feed != nullptr) prep_inputs = feed->prep_inputs();
   HIP_CHECK(hipMemcpyAsync(b.h_slab.p, b.d_slab.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, side));
   HIP_CHECK(hipEventRecord(b.run1_slab, side));
+  HIP_CHECK(hipMemsetAsync(b.d_slab.p, 0, 2 * sizeof(int32_t), side));
   HIP_CHECK(hipMemsetAsync(oh_ml, 0, vol * sizeof(float), side));            // self%OH_ML(:,:,:) = 0.0 (:1559)
-  if (prep_inputs != nullptr) HIP_CHECK(hipStreamWaitEvent(stream, prep_inputs, 0));
+  // A kernel that needs a list of the feed waits for it in one of two ways.  Enqueued behind a wait on the list's event
+  // (hipStreamWaitEvent: a barrier packet on this queue that the command processor re-examines at its leisure - the
+  // kernel behind it started 21-38 us after the copy had ended, profiles/r05_run1_timeline_block_48x24.txt), or GATED:
+  // this thread waits for the event and launches then (a few us).  The feed says which (host form with registered
+  // arrays: gated; a tick is a third of a millisecond and has two such waits on its critical path).
+  if (prep_inputs != nullptr && !gated) HIP_CHECK(hipStreamWaitEvent(stream, prep_inputs, 0));
 
   // pieces: as many as the slab's tiles make whole launches of the ring kernel (at its most, all km levels), of whole
   // rows of bricks (four j); the pieces' extents do not depend on the slab count, which is not known yet
@@ -1696,9 +1794,9 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
     HIP_CHECK(launch_post_process(p, s));
   };
 
-  prep_piece(0, stream);
+  if (!gated) prep_piece(0, stream);
   if (npieces > 1) {
-    if (prep_inputs != nullptr) HIP_CHECK(hipStreamWaitEvent(side, prep_inputs, 0));      // later pieces' features run here
+    if (prep_inputs != nullptr && side != stream) HIP_CHECK(hipStreamWaitEvent(side, prep_inputs, 0));      // later pieces' features run here
     prep_piece(1, side);
     HIP_CHECK(hipEventRecord(b.run1_prep[1], side));
   }
@@ -1716,9 +1814,17 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   const int k1 = r.km - slab[0] + 1, k2 = r.km;   // 1-based (:300-301)
   if (r.k1) *r.k1 = k1;
   if (r.k2) *r.k2 = k2;
-  hipEvent_t post_inputs = nullptr;
-  if (feed != nullptr) HIP_CHECK(hipStreamWaitEvent(stream, feed->walk_inputs(k1, k2), 0));
+  hipEvent_t post_inputs = nullptr, walk_inputs = nullptr;
+  if (feed != nullptr) walk_inputs = feed->walk_inputs(k1, k2);
   TICK_MARK("walk-inputs-enqueued");
+  if (gated) {
+    // (the walk's list is on its way before this thread waits for the features': the link is not idle meanwhile)
+    HIP_CHECK(hipEventSynchronize(prep_inputs));
+    prep_piece(0, stream);
+    TICK_MARK("features-launched");
+  } else if (walk_inputs != nullptr) {
+    HIP_CHECK(hipStreamWaitEvent(stream, walk_inputs, 0));
+  }
 
   const float* fields[27] = {r.lat_deg, pl_bst, r.t_bst, r.no2, r.o3, r.ch4, r.co, r.isop, r.acet, r.c2h6, r.c3h8,
                              r.prpe, r.alk4, r.mp, r.h2o2, tauclwdn, tauclidn, taucliup, tauclwup, r.cloud, r.qv,
@@ -1726,8 +1832,10 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   static const int32_t is2d[27] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};
   if (kind == KernelKind::Wide) ensure_wide(b);
   // OH_ML := 0 (side stream) lies before the first store of a walk
-  HIP_CHECK(hipEventRecord(b.run1_join, side));
-  HIP_CHECK(hipStreamWaitEvent(stream, b.run1_join, 0));
+  if (side != stream) {
+    HIP_CHECK(hipEventRecord(b.run1_join, side));
+    HIP_CHECK(hipStreamWaitEvent(stream, b.run1_join, 0));
+  }
   for (int q = 0; q < npieces; ++q) {
     const int jq = j_lo[(size_t)q + 1] - j_lo[(size_t)q];
     const uint64_t first = (uint64_t)j_lo[(size_t)q] * (uint64_t)r.im;        // the piece's first column
@@ -1754,6 +1862,10 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
       LaunchTuning tune = b.tune;
       leaf_room(b, slab_rows, fa.tree_end - fa.tree_begin, tune, r.im, jq, 0);
       const bool deferring = defer_prepare(b, slab_rows, tune, stream);
+      if (gated && q == 0) {
+        HIP_CHECK(hipEventSynchronize(walk_inputs));
+        TICK_MARK("walk-inputs-there");
+      }
       HIP_CHECK(launch_predict_fields(kind, device_forest(b), fa, b.dev.num_cus, stream, tune));
       if (deferring && q + 1 == npieces) defer_look(b, slab_rows, stream);
     }
@@ -1774,7 +1886,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
       HIP_CHECK(hipEventRecord(b.run1_prep[(size_t)q + 2], side));
     }
   }
-  if (npieces > 1) {       // the caller's stream ends behind everything the side stream did
+  if (npieces > 1 && side != stream) {       // the caller's stream ends behind everything the side stream did
     HIP_CHECK(hipEventRecord(b.run1_join, side));
     HIP_CHECK(hipStreamWaitEvent(stream, b.run1_join, 0));
   }
@@ -1839,7 +1951,8 @@ int OHXOHPostProcess(int im, int jm, int km, float avogad, float runiv, float ep
   }
   const float* src[6] = {ple_mod, t_mod, q_mod, tropp_mod, default_oh, oh_ml};
   const size_t n[6] = {edge, vol, vol, plane, vol, vol};
-  HostMover in(nullptr, true);
+  hipStream_t st = lib_streams(dev.ordinal).exec;
+  HostMover in(st, true);
   for (int i = 0; i < 6; ++i) {
     g_post.buf[i].ensure(n[i]);
     in.add(g_post.buf[i].p, src[i], n[i]);
@@ -1849,12 +1962,12 @@ int OHXOHPostProcess(int im, int jm, int km, float avogad, float runiv, float ep
   if (ndwet) g_post.buf[7].ensure(vol);
   HIP_CHECK(launch_post_process(post_args(im, jm, km, avogad, runiv, epsilon, g_post.buf[0].p, g_post.buf[1].p,
                                           g_post.buf[2].p, g_post.buf[3].p, g_post.buf[4].p, g_post.buf[5].p,
-                                          g_post.buf[6].p, ndwet ? g_post.buf[7].p : nullptr), nullptr));
-  HostMover back(nullptr, false);
+                                          g_post.buf[6].p, ndwet ? g_post.buf[7].p : nullptr), st));
+  HostMover back(st, false);
   back.add(oh, g_post.buf[6].p, vol);
   if (ndwet) back.add(ndwet, g_post.buf[7].p, vol);
   back.go();
-  HIP_CHECK(hipStreamSynchronize(nullptr));
+  HIP_CHECK(hipStreamSynchronize(st));
   API_END();
 }
 
@@ -1895,13 +2008,14 @@ int OHXSolarGeometry(int jday, const float* lats, const float* lons, int im, int
   if (plane == 0) return 0;
   if (lats == nullptr || (sza_noon != nullptr && lons == nullptr))
     throw OhxError("OHXSolarGeometry: LATS (and LONS, for the zenith angle) must not be NULL");
-  use_device(-1);
+  const DeviceInfo dev = use_device(-1);
+  hipStream_t st = lib_streams(dev.ordinal).exec;
   DevBuf<float> d_lats, d_lons, d_lat, d_sza;
   d_lats.ensure(plane);
-  HIP_CHECK(hipMemcpy(d_lats.p, lats, plane * sizeof(float), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpyAsync(d_lats.p, lats, plane * sizeof(float), hipMemcpyHostToDevice, st));
   if (sza_noon) {
     d_lons.ensure(plane);
-    HIP_CHECK(hipMemcpy(d_lons.p, lons, plane * sizeof(float), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpyAsync(d_lons.p, lons, plane * sizeof(float), hipMemcpyHostToDevice, st));
     d_sza.ensure(plane);
   }
   if (lat_deg) d_lat.ensure(plane);
@@ -1911,9 +2025,10 @@ int OHXSolarGeometry(int jday, const float* lats, const float* lons, int im, int
   a.lats = d_lats.p; a.lons = d_lons.p;
   a.lat_deg = lat_deg ? d_lat.p : nullptr;
   a.sza_noon = sza_noon ? d_sza.p : nullptr;
-  HIP_CHECK(launch_solar_geometry(a, nullptr));
-  if (lat_deg) HIP_CHECK(hipMemcpy(lat_deg, d_lat.p, plane * sizeof(float), hipMemcpyDeviceToHost));
-  if (sza_noon) HIP_CHECK(hipMemcpy(sza_noon, d_sza.p, plane * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_CHECK(launch_solar_geometry(a, st));
+  if (lat_deg) HIP_CHECK(hipMemcpyAsync(lat_deg, d_lat.p, plane * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (sza_noon) HIP_CHECK(hipMemcpyAsync(sza_noon, d_sza.p, plane * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));        // before the device buffers go
   API_END();
 }
 
@@ -1948,10 +2063,6 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
       {h.cloud, &d.cloud, vol, 3}, {h.qv, &d.qv, vol, 3}, {h.ch2o, &d.ch2o, vol, 3}};
   constexpr size_t nin = sizeof(ins) / sizeof(ins[0]);
   if (b->d_run1_stage.size() < nin + 3 + 9) b->d_run1_stage.resize(nin + 3 + 9);
-  if (b->s_copy == nullptr) {
-    HIP_CHECK(hipStreamCreateWithFlags(&b->s_copy, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&b->s_exec, hipStreamNonBlocking));
-  }
   // an array handed over twice is staged once: the later entry takes the earlier one's device copy - and its stage,
   // if that one crosses in full (a stage-3 entry shares only with a full copy, never the other way round)
   int same_as[nin];
@@ -2014,6 +2125,18 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
       HIP_CHECK(hipEventRecord(ev[3], b->s_copy));
       return ev[3];
     }
+    bool in_place = true, gate = false;
+    bool slab_in_place(const float** ple, const float** tropp) override {
+      if (!in_place) return false;
+      void *mp = nullptr, *mt = nullptr;           // ins[0], ins[1]: the model's PLE and TROPP
+      if (!g_host_registry.want(ins[0].host, ins[0].n * sizeof(float), &mp) || mp == nullptr) return false;
+      if (!g_host_registry.want(ins[1].host, ins[1].n * sizeof(float), &mt) || mt == nullptr) return false;
+      *ple = static_cast<const float*>(mp);
+      *tropp = static_cast<const float*>(mt);
+      ins[0].stage = ins[1].stage = 1;             // their device copies (the last kernel's) cross with the next list
+      return true;
+    }
+    bool host_gated() const override { return gate; }
   } feed;
   feed.b = b;
   feed.ins = ins;
@@ -2057,7 +2180,16 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
     b->d_run1_stage[nin + 3 + i].ensure(outs[i].n);
     *outs[i].dev = b->d_run1_stage[nin + 3 + i].p;
   }
-  static const int nstreams = [] { const char* e = getenv("OHX_RUN1_STREAMS"); return e ? atoi(e) : 3; }();
+  // experiment knobs, read once (profiles/r05_sweeps.txt has what each is worth): OHX_RUN1_STREAMS=1 puts the copies on
+  // the kernels' stream; OHX_RUN1_GATE=1 launches every kernel when this thread has seen its list's event instead of
+  // enqueueing it behind a wait on the event; OHX_RUN1_SLAB_IN_PLACE=1 lets the slab count read PLE and TROPP over PCIe
+  static const int nstreams = [] { const char* e = getenv("OHX_RUN1_STREAMS"); return e ? atoi(e) : 2; }();
+  // (both measured worth nothing on a rank's block - 0.312 ms off / off, 0.314 in place, 0.319 gated and in place: the front
+  // of a tick is bound by the link, 9.4 MB in 178 us, whatever the kernels wait for - and so both are off)
+  static const bool knob_gate = [] { const char* e = getenv("OHX_RUN1_GATE"); return e && e[0] == '1'; }();
+  static const bool knob_in_place = [] { const char* e = getenv("OHX_RUN1_SLAB_IN_PLACE"); return e && e[0] == '1'; }();
+  feed.gate = knob_gate && nstreams != 1 && g_host_registry.on.load(std::memory_order_relaxed);
+  feed.in_place = knob_in_place;
   hipStream_t main = nstreams == 1 ? b->s_copy : b->s_exec;
   static const bool tracing = getenv("OHX_RUN1_TRACE") != nullptr;
   static std::atomic<unsigned> tick_no{0};
@@ -2080,9 +2212,23 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   if (h.oh_boost) back.add(h.oh_boost, d.oh_boost, vol);
   for (size_t i = 0; i < nout; ++i)
     if (outs[i].host) back.add(outs[i].host, *outs[i].dev, outs[i].n);
+  // the kernels' flag words come back on the same launch (a read-back of their own was one more launch at a tick's end)
+  b->h_flags.ensure(2);
+  void* flags_there = nullptr;          // where the GPU reaches the pinned words
+  if (hipHostGetDevicePointer(&flags_there, b->h_flags.p, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    flags_there = nullptr;
+  }
+  const bool flags_ride = flags_there != nullptr && back.ride(flags_there, b->d_flags.p, 2);
   back.go();
   TICK_MARK("all-enqueued");
-  raise_flag_errors(*b, main);          // waits for the stream: the outputs are in the caller's arrays
+  if (flags_ride) {
+    HIP_CHECK(hipStreamSynchronize(main));          // the outputs are in the caller's arrays
+    const uint32_t flags[2] = {b->h_flags.p[0], b->h_flags.p[1]};
+    judge_flags(*b, flags, main);
+  } else {
+    raise_flag_errors(*b, main);        // waits for the stream
+  }
   TICK_MARK("done");
   if (g_tick_trace) g_tick_trace->print(tick);
   g_tick_trace = nullptr;

@@ -60,6 +60,8 @@ program oh_gridcomp_driver
    integer(c_int32_t) :: im, jm, km, n4, nrec, kind
    integer :: rc, u, uo, us, nticks, tick, i, c, q, beg_date, beg_time, dt, nymd, nhms, yy, mm, dd, h, m, s, nwant, trc
    integer :: avg24_tick, k1, k2, ninst
+   integer(kind=8) :: clock0, clock1, clock_rate
+   character(len=16) :: timing
    logical :: ran, boosted, running
    real, pointer :: p2(:,:), p3(:,:,:), p4(:,:,:,:), oh(:,:,:), parent_oh(:,:,:)
    real, allocatable :: buf(:), lats(:,:), lons(:,:)
@@ -180,13 +182,18 @@ program oh_gridcomp_driver
    ninst = size(gcs)
    open(newunit=uo, file=trim(out_file), access='stream', form='unformatted', status='replace', action='write')
    write(uo) int(nticks, c_int32_t), int(ninst, c_int32_t), int(nwant, c_int32_t)
+   !  OHX_DRIVER_TIMING in the environment: the wall time of every tick's two run phases on stdout, "TICK_US <tick> <us>"
+   call get_environment_variable('OHX_DRIVER_TIMING', timing)
    do tick = 0, nticks - 1
       if (tick > 0) call model_moves()
       if (tick == avg24_tick) call daily_means_arrive()
+      call system_clock(clock0, clock_rate)
       call ESMF_GridCompRun(root, clock=clock, phase=1, rc=rc)
       if (rc /= ESMF_SUCCESS) call die('Run phase 1 failed')
       call ESMF_GridCompRun(root, clock=clock, phase=2, rc=rc)
       if (rc /= ESMF_SUCCESS) call die('Run phase 2 failed')
+      call system_clock(clock1)
+      if (len_trim(timing) > 0) print '(a,i0,1x,f0.1)', 'TICK_US ', tick, real(clock1 - clock0, 8) * 1.0d6 / real(clock_rate, 8)
       call ESMF_ClockGet(clock, currTime=now)
       call ESMF_TimeGet(now, YY=yy, MM=mm, DD=dd, H=h, M=m, S=s)
       call MAPL_PackTime(nymd, yy, mm, dd)

@@ -19,6 +19,7 @@ What this does NOT do: pin xgboost.  Under both children the trees are walked by
 reference holds no xgboost arithmetic.  PARITY WITH libxgboost 1.6.0 STAYS UNPINNED.
 
 Skipped where oracle/_ref/refchild is not built (no /root/reference and no prebuilt files)."""
+import json
 import os
 
 import numpy as np
@@ -56,7 +57,7 @@ def avg24_imports(grid, seed=3):
     return imports, lats, lons
 
 
-def run_both(tmp_path, small_model, ref_exe, product_exe, *, grid, source, nticks, seed=3, **cfg):
+def run_both(tmp_path, small_model, ref_exe, product_exe, *, grid, source, nticks, seed=3, exports=None, **cfg):
     """The same run directory and state file through the reference's child and the product's shell."""
     imports, lats, lons = avg24_imports(grid, seed) if source == "ONLINE_AVG24" else tg.mock_imports(grid, source, seed=seed)
     other = synth.make_model(num_trees=20, max_depth=10, sample_log2=15, min_leaf=4, grid=synth.GRIDS["C12"], model_seed=77)
@@ -64,20 +65,22 @@ def run_both(tmp_path, small_model, ref_exe, product_exe, *, grid, source, ntick
     (tmp_path / "oh_M02.model").write_bytes(other.image.tobytes())
     rundir, state = tmp_path / "run", tmp_path / "state.bin"
     # policy "reference": the reference's child loads the first file for good (:209,269), so the product is told to as well
+    want = EXPORTS if exports is None else exports
     tg.write_rundir(rundir, source=source, model_pattern=str(tmp_path / "oh_M%m2.model"), policy="reference",
-                    exports=[e for e, _ in EXPORTS], **cfg)
+                    exports=[e for e, _ in want], **cfg)
     tg.write_state_file(state, grid, imports, lats, lons)
     out = {}
     for tag, exe in (("reference", ref_exe), ("product", product_exe)):
         r = tg.run_driver(exe, rundir, state, tmp_path / f"{tag}.bin", nticks)
         assert r.returncode == 0, (tag, r.stdout[-3000:])
-        out[tag] = (tg.parse_output(tmp_path / f"{tag}.bin", grid, [("OH", False)], EXPORTS), r.stdout)
+        out[tag] = (tg.parse_output(tmp_path / f"{tag}.bin", grid, [("OH", False)], want), r.stdout)
     return out, imports, lats, lons, {1: small_model.image, 2: other.image}
 
 
-def compare(ref_ticks, prod_ticks, tolerance=None):
+def compare(ref_ticks, prod_ticks, tolerance=None, exports=None):
     """Tick by tick, field by field; `tolerance` maps a field to the ulps it may differ by (default: bit for bit)."""
     tolerance = tolerance or {}
+    exports = EXPORTS if exports is None else exports
     assert len(ref_ticks) == len(prod_ticks)
     boosts = 0
     for a, b in zip(ref_ticks, prod_ticks):
@@ -86,7 +89,7 @@ def compare(ref_ticks, prod_ticks, tolerance=None):
         assert ra["ran"] is True and ra["k1"] == -1            # -1 on file: the reference's child does not say what it did
         assert ra["parent_export_ok"] == pb["parent_export_ok"] == 1
         boosts += pb["boosted"]
-        for name in ["OH"] + [e for e, _ in EXPORTS]:
+        for name in ["OH"] + [e for e, _ in exports]:
             x, y = ra[name], pb[name]
             if name in tolerance:
                 worst = int(helpers.ulp_diff(x, y).max())
@@ -259,3 +262,40 @@ def test_reference_child_and_product_shell_on_a_block_the_ring_kernels_take(tmp_
     (ref, _), (prod, _) = out["reference"], out["product"]
     assert compare(ref, prod, tolerance=POW10) == 1
     assert np.count_nonzero(prod[0]["OH"]["OH_boost"]) > 200_000
+
+
+def tick_times_us(stdout):
+    return [float(ln.split()[2]) for ln in stdout.splitlines() if ln.startswith("TICK_US ")]
+
+
+@pytest.mark.gpu
+def test_a_rank_s_oh_tick_end_to_end_reference_child_and_product_shell(tmp_path, deep_model, monkeypatch):
+    """What switching buys a GEOS rank, measured where the rank sees it: the wall time of Run1 + Run2 of one OH tick on a
+    48 x 24 x 72 block (NOTES.wiki's rank size), every tick a Boost tick, HISTORY asking for no DIAG export.
+      reference child: the reference's own OH_GridCompMod.F90 - feature engineering (:1444-1482, the O(km^2) column sums), the
+        gather (:308-345), 10**x, mask and conversion on the rank's core; the five xgboost calls into libohxgb.so on the GPU
+      product shell:   quickchem_amd/fortran/oh_gridcomp.F90 - one OHXBoosterRun1 per tick, arrays registered
+    Same parent, same state file, same model, same GPU; the two runs agree as the smaller cases above do.  The numbers go
+    to gpurun_out/ (profiles/r05_rank_tick_end_to_end.json is a copy); the assertion is only that the product's tick is
+    the shorter one."""
+    monkeypatch.setenv("OHX_DRIVER_TIMING", "1")
+    grid = (48, 24, 72)
+    kw = dict(grid=grid, source="ONLINE_INST", nticks=40, seed=21, once_per_day=False, spinup=False, run_dt=1800,
+              oh_dt=1800, avg24_tick=-1, ohscale=0.85, ref_time="000000", beg="20240131 000000", exports=[])
+    out, *_ = run_both(tmp_path, deep_model, REF_HIP, tg.DRIVER_HIP, **kw)
+    (ref, ref_log), (prod, prod_log) = out["reference"], out["product"]
+    assert compare(ref, prod, tolerance=POW10, exports=[]) == 40
+    t_ref, t_prod = tick_times_us(ref_log)[5:], tick_times_us(prod_log)[5:]
+    assert len(t_ref) == len(t_prod) == 35
+    med = lambda xs: float(np.median(xs))
+    record = {"block": list(grid), "ticks_timed": 35, "data_source": "ONLINE_INST", "booster": "100 trees, depth <= 18 (synthetic)",
+              "slab_levels": [int(prod[-1]["OH"]["k1"]), int(prod[-1]["OH"]["k2"])],
+              "reference_child_tick_us": {"median": med(t_ref), "min": min(t_ref), "max": max(t_ref)},
+              "product_shell_tick_us": {"median": med(t_prod), "min": min(t_prod), "max": max(t_prod)},
+              "what": "wall time of ESMF_GridCompRun phase 1 + 2 of the parent per tick, one rank alone on the GPU; reference child = "
+                      "OH_GridCompMod.F90 compiled in place, its five xgboost calls served by libohxgb.so"}
+    print("RANK_TICK " + json.dumps(record))
+    outdir = os.path.join(helpers.ROOT, "gpurun_out")
+    if os.path.isdir(outdir) and os.access(outdir, os.W_OK):
+        json.dump(record, open(os.path.join(outdir, "rank_tick_end_to_end.json"), "w"), indent=1)
+    assert med(t_prod) < med(t_ref)
