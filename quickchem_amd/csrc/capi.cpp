@@ -2191,11 +2191,13 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   feed.gate = knob_gate && nstreams != 1 && g_host_registry.on.load(std::memory_order_relaxed);
   feed.in_place = knob_in_place;
   hipStream_t main = nstreams == 1 ? b->s_copy : b->s_exec;
-  static const bool tracing = getenv("OHX_RUN1_TRACE") != nullptr;
+  // OHX_RUN1_TRACE=<n> (1 = 50): the host's time marks of ticks n .. n + 2 of this process on stderr
+  static const int trace_from = [] { const char* e = getenv("OHX_RUN1_TRACE"); const int n = e ? atoi(e) : -1; return n == 1 ? 50 : n; }();
+  const bool tracing = trace_from >= 0;
   static std::atomic<unsigned> tick_no{0};
   TickTrace trace;
   const unsigned tick = tick_no.fetch_add(1);
-  g_tick_trace = (tracing && tick >= 50 && tick <= 52) ? &trace : nullptr;
+  g_tick_trace = (tracing && tick >= (unsigned)trace_from && tick <= (unsigned)trace_from + 2u) ? &trace : nullptr;
   TICK_MARK("set-up");
   try {
     run1_device(*b, d, main, &feed);

@@ -518,8 +518,21 @@ contains
    !  a global max/min print (a reduction over ranks in MAPL; OH_GridCompMod.F90:1550)
    subroutine MAPL_MaxMin(label, a)
       character(len=*), intent(in) :: label
-      real, intent(in) :: a(:,:,:)
-      if (MAPL_AM_I_ROOT()) print '(a,2es16.7)', trim(label)//' max, min = ', maxval(a), minval(a)
+      real, intent(in), contiguous :: a(:,:,:)
+      real :: hi, lo
+      integer :: i, j, k
+      if (.not. MAPL_AM_I_ROOT()) return
+      !  one pass the compiler vectorises (maxval + minval through the descriptor were 0.4 ms on a rank's 83 k gridcells -
+      !  half of the product shell's tick, and nothing either child computes)
+      hi = -huge(hi); lo = huge(lo)
+      do k = 1, size(a, 3)
+         do j = 1, size(a, 2)
+            do i = 1, size(a, 1)
+               hi = max(hi, a(i,j,k)); lo = min(lo, a(i,j,k))
+            end do
+         end do
+      end do
+      print '(a,2es16.7)', trim(label)//' max, min = ', hi, lo
    end subroutine
 
 end module MAPL
