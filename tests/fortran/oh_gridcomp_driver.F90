@@ -62,6 +62,8 @@ program oh_gridcomp_driver
    integer :: avg24_tick, k1, k2, ninst
    integer(kind=8) :: clock0, clock1, clock_rate
    character(len=16) :: timing
+   character(len=32) :: meet_at
+   real(kind=8) :: meet_sod
    logical :: ran, boosted, running
    real, pointer :: p2(:,:), p3(:,:,:), p4(:,:,:,:), oh(:,:,:), parent_oh(:,:,:)
    real, allocatable :: buf(:), lats(:,:), lons(:,:)
@@ -184,8 +186,14 @@ program oh_gridcomp_driver
    write(uo) int(nticks, c_int32_t), int(ninst, c_int32_t), int(nwant, c_int32_t)
    !  OHX_DRIVER_TIMING in the environment: the wall time of every tick's two run phases on stdout, "TICK_US <tick> <us>"
    call get_environment_variable('OHX_DRIVER_TIMING', timing)
+   !  OHX_DRIVER_MEET_AT=<seconds of the day, UTC>: after tick 0 (which loads the model) wait for that time - several
+   !  drivers started together then tick together, as the ranks of a model do
+   call get_environment_variable('OHX_DRIVER_MEET_AT', meet_at)
+   meet_sod = -1.0d0
+   if (len_trim(meet_at) > 0) read(meet_at, *) meet_sod
    do tick = 0, nticks - 1
       if (tick > 0) call model_moves()
+      if (tick == 1 .and. meet_sod >= 0.0d0) call wait_until(meet_sod)
       if (tick == avg24_tick) call daily_means_arrive()
       call system_clock(clock0, clock_rate)
       call ESMF_GridCompRun(root, clock=clock, phase=1, rc=rc)
@@ -236,6 +244,15 @@ program oh_gridcomp_driver
    close(uo)
 
 contains
+
+   subroutine wait_until(sod)
+      real(kind=8), intent(in) :: sod
+      integer :: v(8)
+      do
+         call date_and_time(values=v)
+         if (real(v(5) * 3600 + v(6) * 60 + v(7), 8) + real(v(8), 8) * 1.0d-3 - real(v(4), 8) * 60.0d0 >= sod) exit
+      end do
+   end subroutine
 
    !  The parent's SetServices is the reference's own routine, whose RC is OPTIONAL (QuickChem_GridCompMod.F90:78-83);
    !  GEOS hands such routines on as `external` procedures (as the parent itself does with its children's, :516-531)

@@ -299,3 +299,49 @@ def test_a_rank_s_oh_tick_end_to_end_reference_child_and_product_shell(tmp_path,
     if os.path.isdir(outdir) and os.access(outdir, os.W_OK):
         json.dump(record, open(os.path.join(outdir, "rank_tick_end_to_end.json"), "w"), indent=1)
     assert med(t_prod) < med(t_ref)
+
+
+@pytest.mark.gpu
+def test_six_ranks_on_the_gpu_end_to_end_reference_child_and_product_shell(tmp_path, deep_model, monkeypatch):
+    """The same measurement the way a GEOS node runs: SIX ranks, each a process with a 48 x 24 x 72 block of its own, sharing
+    the one GPU (NOTES.wiki:14,33: a rank per core; gpurun's process guard allows six).  Six copies of the reference child's
+    driver, then six of the product shell's, started together and held at a common time after their first tick; every
+    later tick of every rank is timed (wall time of the parent's two run phases).  Written to gpurun_out/
+    (profiles/r05_six_ranks_end_to_end.json is a copy); asserted: the product's median tick is the shorter."""
+    import subprocess
+    import time
+    monkeypatch.setenv("OHX_DRIVER_TIMING", "1")
+    grid, nticks, P = (48, 24, 72), 60, 6
+    imports, lats, lons = tg.mock_imports(grid, "ONLINE_INST", seed=21)
+    (tmp_path / "oh_M01.model").write_bytes(deep_model.image.tobytes())
+    rundir, state = tmp_path / "run", tmp_path / "state.bin"
+    tg.write_rundir(rundir, source="ONLINE_INST", model_pattern=str(tmp_path / "oh_M01.model"), policy="reference", exports=[],
+                    once_per_day=False, spinup=False, run_dt=1800, oh_dt=1800, avg24_tick=-1, ohscale=0.85,
+                    ref_time="000000", beg="20240131 000000")
+    tg.write_state_file(state, grid, imports, lats, lons)
+    record = {"block": list(grid), "ranks": P, "ticks_per_rank": nticks - 1, "data_source": "ONLINE_INST",
+              "what": "six driver processes on one GPU, ticking together from their second tick on; per-tick wall time of the "
+                      "parent's two run phases over all ranks, us"}
+    medians = {}
+    for tag, exe in (("reference_child", REF_HIP), ("product_shell", tg.DRIVER_HIP)):
+        now = time.gmtime(time.time() + 12.0)
+        env = dict(os.environ, OHX_DRIVER_MEET_AT=str(now.tm_hour * 3600 + now.tm_min * 60 + now.tm_sec))
+        procs = [subprocess.Popen([exe, str(rundir), str(state), str(tmp_path / f"{tag}_{r}.bin"), str(nticks)], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(P)]
+        ticks = []
+        for p in procs:
+            out, _ = p.communicate(timeout=600)
+            assert p.returncode == 0, (tag, out[-2000:])
+            ticks += tick_times_us(out)[1:]
+        for r in range(P):
+            os.remove(tmp_path / f"{tag}_{r}.bin")
+        assert len(ticks) == P * (nticks - 1)
+        ticks.sort()
+        medians[tag] = ticks[len(ticks) // 2]
+        record[tag + "_tick_us"] = {"median": medians[tag], "p10": ticks[len(ticks) // 10], "p90": ticks[len(ticks) * 9 // 10],
+                                    "p99": ticks[len(ticks) * 99 // 100], "max": ticks[-1], "mean": sum(ticks) / len(ticks)}
+    print("SIX_RANKS " + json.dumps(record))
+    outdir = os.path.join(helpers.ROOT, "gpurun_out")
+    if os.path.isdir(outdir) and os.access(outdir, os.W_OK):
+        json.dump(record, open(os.path.join(outdir, "six_ranks_end_to_end.json"), "w"), indent=1)
+    assert medians["product_shell"] < medians["reference_child"]
