@@ -445,8 +445,8 @@ CheckScratch g_check;
 
 struct DMatrixObj {
   ~DMatrixObj() {
-    // XGBoosterPredict has waited for its kernels; OHXBoosterPredictDevice only enqueues, and the next
-    // XGDMatrixCreateFromMat copies into a parked buffer on the null stream: not before the readers are done
+    // XGBoosterPredict has waited for its kernels; OHXBoosterPredictDevice only enqueues on the caller's stream, and the
+    // next XGDMatrixCreateFromMat copies into a parked buffer on the library's: not before the readers are done
     if (owned != nullptr && used_async) {
       (void)hipSetDevice(device);
       (void)hipDeviceSynchronize();
