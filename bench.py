@@ -336,7 +336,7 @@ def run1_host(booster):
     tick to tick, pageable and with ohx_register_host (registered once, then moved by one copy launch).  The same for
     P ranks sharing the GPU and for a C360/8 block: tools/ranks_per_gpu.py, profiles/r04_ranks_per_gpu*.json."""
     from quickchem_amd import synth
-    out = {"what": "OHXBoosterRun1 host form (and the fused predict-only call, host form), steady-state tick (median of 20 after 3), one process", "blocks": []}
+    out = {"what": "OHXBoosterRun1 host form (and the fused predict-only call, host form), steady-state tick (median of 50 after 13), one process", "blocks": []}
     for block in ((48, 24, 72), (96, 48, 72)):
         st = synth.run1_state(block, seed=5)
         call = booster.run1_prepare(st, dynamic_k_range=True)
@@ -346,11 +346,11 @@ def run1_host(booster):
         for mode, key in (("0", "pageable_ms"), ("1", "registered_ms")):
             booster.set_param("ohx_register_host", mode)
             ticks = []
-            for _ in range(23):
+            for _ in range(63):
                 t0 = time.perf_counter()
                 r = booster.run1_call(call)
                 ticks.append(time.perf_counter() - t0)
-            entry[key] = float(np.median(ticks[3:])) * 1e3
+            entry[key] = float(np.median(ticks[13:])) * 1e3
             if ref is None:
                 ref = r["oh"].copy()
                 entry["levels_predicted"] = int(r["k2"] - r["k1"] + 1)
@@ -363,11 +363,11 @@ def run1_host(booster):
         for mode, key in (("0", "fused_call_pageable_ms"), ("1", "fused_call_registered_ms")):
             booster.set_param("ohx_register_host", mode)
             ticks = []
-            for _ in range(23):
+            for _ in range(63):
                 t0 = time.perf_counter()
                 booster.predict_fields(fields, synth.IS2D, synth.PL_FEATURE, im, jm, km, 1, km, synth.XX_MISS, oh, ohscale=0.85)
                 ticks.append(time.perf_counter() - t0)
-            entry[key] = float(np.median(ticks[3:])) * 1e3
+            entry[key] = float(np.median(ticks[13:])) * 1e3
         out["blocks"].append(entry)
     booster.set_param("ohx_register_host", "0")
     booster.lib.OHXReleaseScratch()
