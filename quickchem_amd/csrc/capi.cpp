@@ -1736,8 +1736,8 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   // A kernel that needs a list of the feed waits for it in one of two ways.  Enqueued behind a wait on the list's event
   // (hipStreamWaitEvent: a barrier packet on this queue that the command processor re-examines at its leisure - the
   // kernel behind it started 21-38 us after the copy had ended, profiles/r05_run1_timeline_block_48x24.txt), or GATED:
-  // this thread waits for the event and launches then (a few us).  The feed says which (host form with registered
-  // arrays: gated; a tick is a third of a millisecond and has two such waits on its critical path).
+  // this thread waits for the event and launches then (a few us).  The feed says which.  Measured on a rank's tick: no
+  // difference - the barriers' delay lies under the link's time (OHXBoosterRun1 below) - so nothing is gated by default.
   if (prep_inputs != nullptr && !gated) HIP_CHECK(hipStreamWaitEvent(stream, prep_inputs, 0));
 
   // pieces: as many as the slab's tiles make whole launches of the ring kernel (at its most, all km levels), of whole
