@@ -359,6 +359,17 @@ def test_host_forms_with_registered_arrays(small_model):
                                    dynamic_k_range=True)
         assert np.array_equal(helpers.bits(aliased["ndwet"]), helpers.bits(want_aliased["ndwet"]))
         assert helpers.ulp_diff(aliased["oh"], want_aliased["oh"]).max() <= 3
+        # the kernels' flag words come back on the copy-back launch of a registered tick: an inf among the inputs is still an
+        # error (xgboost's "Input data contains `inf` or `nan`"), and the tick after it is clean again
+        no2 = call["keep"]["no2"]
+        spot = np.unravel_index(no2.size - 3, no2.shape)          # (the bottom level: inside every slab)
+        was = no2[spot]
+        no2[spot] = np.inf
+        with pytest.raises(capi.OhxError, match="inf"):
+            b.run1_call(call)
+        no2[spot] = was
+        got = b.run1_call(call)
+        assert np.array_equal(helpers.bits(got["oh"]), helpers.bits(plain["oh"]))
         # the post-processing of a tick that skips Boost, host form
         im, jm, km = grid
         flat = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32).T)      # noqa: E731
