@@ -302,16 +302,19 @@ def test_a_rank_s_oh_tick_end_to_end_reference_child_and_product_shell(tmp_path,
 
 
 @pytest.mark.gpu
-def test_six_ranks_on_the_gpu_end_to_end_reference_child_and_product_shell(tmp_path, deep_model, monkeypatch):
-    """The same measurement the way a GEOS node runs: SIX ranks, each a process with a 48 x 24 x 72 block of its own, sharing
-    the one GPU (NOTES.wiki:14,33: a rank per core; gpurun's process guard allows six).  Six copies of the reference child's
-    driver, then six of the product shell's, started together and held at a common time after their first tick; every
-    later tick of every rank is timed (wall time of the parent's two run phases).  Written to gpurun_out/
-    (profiles/r05_six_ranks_end_to_end.json is a copy); asserted: the product's median tick is the shorter."""
+def test_several_ranks_on_the_gpu_end_to_end_reference_child_and_product_shell(tmp_path, deep_model, monkeypatch):
+    """The same measurement the way a GEOS node runs: several ranks, each a process with a 48 x 24 x 72 block of its own,
+    sharing the one GPU (NOTES.wiki:14,33: a rank per core).  P copies of the reference child's driver, then P of the
+    product shell's, started together and held at a common time after their first tick; every later tick of every rank
+    is timed (wall time of the parent's two run phases).  Written to gpurun_out/; asserted: the product's median tick is the
+    shorter.  P = 5 here: the GPU boxes admit six processes on the card and the test runner, which has run GPU tests of
+    its own by now, is one of them.  OHX_E2E_RANKS=6 for a run of this test ALONE (pytest -k several_ranks: the runner
+    then never opens the GPU) - profiles/r05_six_ranks_end_to_end.json was made that way."""
     import subprocess
     import time
     monkeypatch.setenv("OHX_DRIVER_TIMING", "1")
-    grid, nticks, P = (48, 24, 72), 60, 6
+    grid, nticks, P = (48, 24, 72), 60, int(os.environ.get("OHX_E2E_RANKS", "5"))
+    assert 1 <= P <= 6
     imports, lats, lons = tg.mock_imports(grid, "ONLINE_INST", seed=21)
     (tmp_path / "oh_M01.model").write_bytes(deep_model.image.tobytes())
     rundir, state = tmp_path / "run", tmp_path / "state.bin"
@@ -320,7 +323,7 @@ def test_six_ranks_on_the_gpu_end_to_end_reference_child_and_product_shell(tmp_p
                     ref_time="000000", beg="20240131 000000")
     tg.write_state_file(state, grid, imports, lats, lons)
     record = {"block": list(grid), "ranks": P, "ticks_per_rank": nticks - 1, "data_source": "ONLINE_INST",
-              "what": "six driver processes on one GPU, ticking together from their second tick on; per-tick wall time of the "
+              "what": "that many driver processes on one GPU, ticking together from their second tick on; per-tick wall time of the "
                       "parent's two run phases over all ranks, us"}
     medians = {}
     for tag, exe in (("reference_child", REF_HIP), ("product_shell", tg.DRIVER_HIP)):
@@ -340,8 +343,8 @@ def test_six_ranks_on_the_gpu_end_to_end_reference_child_and_product_shell(tmp_p
         medians[tag] = ticks[len(ticks) // 2]
         record[tag + "_tick_us"] = {"median": medians[tag], "p10": ticks[len(ticks) // 10], "p90": ticks[len(ticks) * 9 // 10],
                                     "p99": ticks[len(ticks) * 99 // 100], "max": ticks[-1], "mean": sum(ticks) / len(ticks)}
-    print("SIX_RANKS " + json.dumps(record))
+    print("RANKS_END_TO_END " + json.dumps(record))
     outdir = os.path.join(helpers.ROOT, "gpurun_out")
     if os.path.isdir(outdir) and os.access(outdir, os.W_OK):
-        json.dump(record, open(os.path.join(outdir, "six_ranks_end_to_end.json"), "w"), indent=1)
+        json.dump(record, open(os.path.join(outdir, "ranks_end_to_end_%d.json" % P), "w"), indent=1)
     assert medians["product_shell"] < medians["reference_child"]
