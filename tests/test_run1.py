@@ -403,3 +403,40 @@ def test_host_forms_with_registered_arrays(small_model):
     finally:
         b.set_param("ohx_register_host", "0")
         b.free()
+
+
+@pytest.mark.gpu
+def test_two_oh_instances_tick_from_two_threads(small_model, deep_model):
+    """Two OH instances in one process (QuickChem_GridComp.rc:22), each driven by its own thread: OHXBoosterRun1's host form
+    on registered arrays, twenty ticks each on blocks of different size.  The two boosters share the library's two streams,
+    the host registry and the copy kernel; every tick of either must be what the same booster gives alone."""
+    import threading
+    jobs = []
+    for k, (model, grid) in enumerate(((small_model, (37, 11, 40)), (deep_model, (48, 24, 72)))):
+        st = helpers.run1_state(grid, seed=40 + k)
+        b = capi.Booster(model_buffer=model.image)
+        call = b.run1_prepare(st, dynamic_k_range=True, want_boost=True, want_ndwet=True)
+        alone = {key: v.copy() for key, v in b.run1_call(call).items() if isinstance(v, np.ndarray)}
+        jobs.append((b, call, alone))
+    jobs[0][0].set_param("ohx_register_host", "1")          # (process-wide)
+    errors = []
+
+    def run(b, call, alone):
+        try:
+            for tick in range(20):
+                got = b.run1_call(call)
+                for key, v in alone.items():
+                    if not np.array_equal(helpers.bits(got[key]), helpers.bits(v)):
+                        errors.append((tick, key))
+        except Exception as e:                      # noqa: BLE001 - reported by the assert below
+            errors.append(repr(e))
+    try:
+        threads = [threading.Thread(target=run, args=j) for j in jobs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        jobs[0][0].set_param("ohx_register_host", "0")
+        capi.check(jobs[0][0].lib, jobs[0][0].lib.OHXReleaseScratch())
+    assert errors == []
