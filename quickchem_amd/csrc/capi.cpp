@@ -406,7 +406,12 @@ struct HostMover {
     return true;
   }
   void go() {
-    HIP_CHECK(launch_copy_arrays(list, stream, g_copy_blocks.load(std::memory_order_relaxed)));
+    // a launch that WRITES the caller's memory runs at a tick's end with nothing beside it to keep from starting, and posted
+    // writes want more waves than reads do: 512 blocks (OHX_COPY_BACK_BLOCKS, read once; 0 = as many as ohx_copy_blocks).
+    // A rank's tick at 64 / 128 / 256 / 512: 0.309 / 0.309 / 0.306 / 0.303 ms (profiles/r05_sweeps.txt)
+    static const int back_blocks = [] { const char* e = getenv("OHX_COPY_BACK_BLOCKS"); return e ? atoi(e) : 512; }();
+    const uint32_t blocks = (!to_device && back_blocks > 0) ? (uint32_t)back_blocks : g_copy_blocks.load(std::memory_order_relaxed);
+    HIP_CHECK(launch_copy_arrays(list, stream, blocks));
     list.count = 0;
     list_bytes = 0;
   }
