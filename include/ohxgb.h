@@ -119,7 +119,9 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *                     is synchronised first).  Default 0 (the OH shell turns it on: register_host_arrays, default T)
  *   "ohx_copy_blocks" process-wide: blocks per launch of the kernel that moves registered host arrays (default 64; 0 = a
  *                     block per KiB).  Small on purpose: a chip full of wavefronts waiting on PCIe moves a rank's arrays
- *                     slower and keeps every other stream's kernels from starting meanwhile
+ *                     slower and keeps every other stream's kernels from starting meanwhile.
+ *                     Launches that WRITE the caller's arrays (a tick's results, at its end) use 512 blocks
+ *                     (OHX_COPY_BACK_BLOCKS in the environment, read once; 0 = as "ohx_copy_blocks")
  *   "ohx_tree_tops"   auto | on | off : super-nodes: fetch a tree's first records with one coalesced load per
  *                     wavefront (auto = forests of 7 or more steps per tree, where it is faster)
  *   "ohx_cluster"     auto | on | off : group rows of no known order by the decisions they take at the top of
