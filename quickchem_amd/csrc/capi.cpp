@@ -359,12 +359,14 @@ struct HostMover {
   size_t list_bytes = 0;
   hipStream_t stream;
   bool to_device;
+  uint32_t blocks_override = 0;       // blocks of this mover's launches, when its owner knows better than the defaults
+  bool by_dma = false;                // registered arrays too go through hipMemcpyAsync (the DMA engines: no wave on a CU)
   explicit HostMover(hipStream_t s, bool h2d) : stream(s), to_device(h2d) {}
   void add(float* dst, const float* src, size_t count) {
     if (count == 0) return;
     const void* host = to_device ? (const void*)src : (const void*)dst;
     void* mapped = nullptr;
-    if (g_host_registry.want(host, count * sizeof(float), &mapped) && mapped != nullptr && list.count < kCopyListMax &&
+    if (g_host_registry.want(host, count * sizeof(float), &mapped) && mapped != nullptr && !by_dma && list.count < kCopyListMax &&
         list_bytes + count * sizeof(float) <= kKernelBytesMax) {
       list.src[list.count] = to_device ? static_cast<const float*>(mapped) : src;
       list.dst[list.count] = to_device ? dst : static_cast<float*>(mapped);
@@ -410,7 +412,8 @@ struct HostMover {
     // writes want more waves than reads do: 512 blocks (OHX_COPY_BACK_BLOCKS, read once; 0 = as many as ohx_copy_blocks).
     // A rank's tick at 64 / 128 / 256 / 512: 0.309 / 0.309 / 0.306 / 0.303 ms (profiles/r05_sweeps.txt)
     static const int back_blocks = [] { const char* e = getenv("OHX_COPY_BACK_BLOCKS"); return e ? atoi(e) : 512; }();
-    const uint32_t blocks = (!to_device && back_blocks > 0) ? (uint32_t)back_blocks : g_copy_blocks.load(std::memory_order_relaxed);
+    uint32_t blocks = (!to_device && back_blocks > 0) ? (uint32_t)back_blocks : g_copy_blocks.load(std::memory_order_relaxed);
+    if (blocks_override > 0) blocks = blocks_override;
     HIP_CHECK(launch_copy_arrays(list, stream, blocks));
     list.count = 0;
     list_bytes = 0;
@@ -2097,8 +2100,14 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
     const bool* whole;
     size_t plane, km;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t post_blocks = 0;
+    bool post_by_dma = false;
     void stage(int which, int k1, int k2) {
       HostMover in(b->s_copy, true);
+      if (which == 2) {
+        in.blocks_override = post_blocks;
+        in.by_dma = post_by_dma;
+      }
       for (size_t i = 0; i < nin; ++i) {
         if (ins[i].stage != which || same_as[i] >= 0) continue;
         float* dev = b->d_run1_stage[i].p;
@@ -2195,6 +2204,16 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   static const bool knob_in_place = [] { const char* e = getenv("OHX_RUN1_SLAB_IN_PLACE"); return e && e[0] == '1'; }();
   feed.gate = knob_gate && nstreams != 1 && g_host_registry.on.load(std::memory_order_relaxed);
   feed.in_place = knob_in_place;
+  // The last list of a tick (what only the mask and the conversion read) crosses UNDER the walk, and a copy kernel is bad
+  // company for a walk: a CU's vector memory path returns in order, so the walk's waves on the CUs where copy waves wait
+  // for PCIe wait with them - with the usual 64 blocks the walk "started" when the 20 us copy ended, with 8 blocks it
+  // started at once and took 116 us instead of 66 (profiles/r05_run1_timeline_block_48x24.txt, r05_sweeps.txt).  So
+  // this one list goes through the DMA engines (three hipMemcpyAsync of registered arrays, 11 us each, no wave on any
+  // CU): a rank's tick 0.301 -> 0.293-0.297 ms.  OHX_COPY_POST_BLOCKS (read once): -1 = DMA (default), 0 = a copy kernel
+  // like the other lists, n = one of n blocks.
+  static const int knob_post_blocks = [] { const char* e = getenv("OHX_COPY_POST_BLOCKS"); return e ? atoi(e) : -1; }();
+  feed.post_blocks = knob_post_blocks > 0 ? (uint32_t)knob_post_blocks : 0u;
+  feed.post_by_dma = knob_post_blocks < 0;
   hipStream_t main = nstreams == 1 ? b->s_copy : b->s_exec;
   // OHX_RUN1_TRACE=<n> (1 = 50): the host's time marks of ticks n .. n + 2 of this process on stderr
   static const int trace_from = [] { const char* e = getenv("OHX_RUN1_TRACE"); const int n = e ? atoi(e) : -1; return n == 1 ? 50 : n; }();
