@@ -2205,9 +2205,10 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   feed.gate = knob_gate && nstreams != 1 && g_host_registry.on.load(std::memory_order_relaxed);
   feed.in_place = knob_in_place;
   // The last list of a tick (what only the mask and the conversion read) crosses UNDER the walk, and a copy kernel is bad
-  // company for a walk: a CU's vector memory path returns in order, so the walk's waves on the CUs where copy waves wait
-  // for PCIe wait with them - with the usual 64 blocks the walk "started" when the 20 us copy ended, with 8 blocks it
-  // started at once and took 116 us instead of 66 (profiles/r05_run1_timeline_block_48x24.txt, r05_sweeps.txt).  So
+  // company for a walk: with the usual 64 blocks the walk "started" when the 20 us copy ended (its packet and arguments are
+  // fetched over the link, behind the copy's queued reads), with 8 blocks it started at once and took 116 us instead of 66
+  // (waves that share a CU with copy waves waiting on PCIe wait with them: a CU's vector memory path returns in order)
+  // (profiles/r05_run1_timeline_block_48x24.txt, r05_sweeps.txt: "copy kernels on CUs of their own" tells the two apart).  So
   // this one list goes through the DMA engines (three hipMemcpyAsync of registered arrays, 11 us each, no wave on any
   // CU): a rank's tick 0.301 -> 0.293-0.297 ms.  OHX_COPY_POST_BLOCKS (read once): -1 = DMA (default), 0 = a copy kernel
   // like the other lists, n = one of n blocks.
