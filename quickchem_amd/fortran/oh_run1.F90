@@ -198,16 +198,21 @@ contains
 
    !  CALL_BOOST and what surrounds it (:1444-1478, 1488, 1557-1595) in one call.
    !  OH is the INTERNAL field (molec/cm3), OH_boost the export OH_ML*OHscale, NDWET the diagnostic.
+   !  want_boost / want_ndwet = .false.: that array is neither filled nor moved (it keeps what it held) - a rank whose
+   !  tick needs neither (Boost on every tick, nobody asking for the OH_boost or DIAG_NDWET exports) gets a third of the
+   !  results' bytes back over PCIe.
    subroutine oh_run1_boost(XGBoostFilename, im, jm, km, dynamic_k_range, tropp_min, OHscale, &
-                            avogad, runiv, epsilon, st, OH, OH_boost, NDWET, k1, k2, rc, diag)
+                            avogad, runiv, epsilon, st, OH, OH_boost, NDWET, k1, k2, rc, diag, want_boost, want_ndwet)
       character(len=*), intent(in) :: XGBoostFilename
       integer, intent(in)  :: im, jm, km
       logical, intent(in)  :: dynamic_k_range
       real, intent(in)     :: tropp_min, OHscale, avogad, runiv, epsilon
       type(OH_RUN1_STATE), intent(in) :: st
-      real, intent(out), target, contiguous :: OH(:,:,:), OH_boost(:,:,:), NDWET(:,:,:)
+      real, intent(out), target, contiguous :: OH(:,:,:)
+      real, intent(inout), target, contiguous :: OH_boost(:,:,:), NDWET(:,:,:)
       integer, intent(out) :: k1, k2, rc
       type(OH_RUN1_DIAG), intent(in), optional :: diag
+      logical, intent(in), optional :: want_boost, want_ndwet
       type(OHXRun1Args) :: a
       type(c_ptr) :: bst
       integer(c_int32_t), target :: ck1, ck2
@@ -253,6 +258,12 @@ contains
          return
       end if
       a%oh = c_loc(OH(1,1,1)); a%oh_boost = c_loc(OH_boost(1,1,1)); a%ndwet = c_loc(NDWET(1,1,1))
+      if (present(want_boost)) then
+         if (.not. want_boost) a%oh_boost = c_null_ptr
+      end if
+      if (present(want_ndwet)) then
+         if (.not. want_ndwet) a%ndwet = c_null_ptr
+      end if
       a%k1 = c_loc(ck1); a%k2 = c_loc(ck2)
       a%diag_pl_bst = c_null_ptr; a%diag_tauclwdn = c_null_ptr; a%diag_tauclidn = c_null_ptr
       a%diag_taucliup = c_null_ptr; a%diag_tauclwup = c_null_ptr; a%diag_aodup = c_null_ptr
