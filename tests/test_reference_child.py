@@ -57,9 +57,11 @@ def avg24_imports(grid, seed=3):
     return imports, lats, lons
 
 
-def run_both(tmp_path, small_model, ref_exe, product_exe, *, grid, source, nticks, seed=3, exports=None, **cfg):
+def run_both(tmp_path, small_model, ref_exe, product_exe, *, grid, source, nticks, seed=3, exports=None, instances=None,
+             extra_imports=None, **cfg):
     """The same run directory and state file through the reference's child and the product's shell."""
     imports, lats, lons = avg24_imports(grid, seed) if source == "ONLINE_AVG24" else tg.mock_imports(grid, source, seed=seed)
+    imports.update(extra_imports or {})
     other = synth.make_model(num_trees=20, max_depth=10, sample_log2=15, min_leaf=4, grid=synth.GRIDS["C12"], model_seed=77)
     (tmp_path / "oh_M01.model").write_bytes(small_model.image.tobytes())
     (tmp_path / "oh_M02.model").write_bytes(other.image.tobytes())
@@ -73,7 +75,7 @@ def run_both(tmp_path, small_model, ref_exe, product_exe, *, grid, source, ntick
     for tag, exe in (("reference", ref_exe), ("product", product_exe)):
         r = tg.run_driver(exe, rundir, state, tmp_path / f"{tag}.bin", nticks)
         assert r.returncode == 0, (tag, r.stdout[-3000:])
-        out[tag] = (tg.parse_output(tmp_path / f"{tag}.bin", grid, [("OH", False)], want), r.stdout)
+        out[tag] = (tg.parse_output(tmp_path / f"{tag}.bin", grid, instances or [("OH", False)], want), r.stdout)
     return out, imports, lats, lons, {1: small_model.image, 2: other.image}
 
 
@@ -176,6 +178,37 @@ def test_reference_child_setservices_registers_its_own_spec_table(tmp_path, smal
         assert set(got) == set(want), sorted(set(got) ^ set(want))
         for key in want:
             assert got[key] == want[key], (source, spinup, key, got[key], want[key])
+
+
+def test_a_passive_data_instance_is_where_the_reference_child_stops_and_the_product_shell_does_not(tmp_path, small_model):
+    """The one place the product's shell deviates from the reference's lines on purpose (header of oh_gridcomp.F90), shown
+    with the reference's own code: a passive data-driven instance (OH.data) beside the active one.  The reference's
+    SetServices registers, for such an instance, the import climoh001 and a 4-D INTERNAL OH (:611-634); its Run_data then
+    takes a 3-D pointer to that field and reads the import oh_OH, which a data instance does not have (:1872,1880) - the
+    run ends at its first tick with the traceback naming those lines.  The product's Run_data follows the registration
+    (and the reference's commented-out lines, :1877-1878,1882): the same run directory goes through, INTERNAL OH of the
+    data instance is the import, bit for bit."""
+    instances = [("OH", False), ("OH.data", True)]
+    grid = (5, 4, 24)
+    imports, lats, lons = tg.mock_imports(grid, "PRECOMPUTED", seed=3)
+    clim = (np.random.default_rng(4).random(grid) * 1e-13).astype(tg.F32)       # the data instance's import (bin 1)
+    imports["climoh001"] = clim
+    (tmp_path / "oh.model").write_bytes(small_model.image.tobytes())
+    rundir, state = tmp_path / "run", tmp_path / "state.bin"
+    tg.write_rundir(rundir, source="PRECOMPUTED", model_pattern=str(tmp_path / "oh.model"), policy="reference",
+                    exports=["OH_boost"], once_per_day=True, spinup=False, run_dt=1800, oh_dt=3600, avg24_tick=-1,
+                    ohscale=0.85, ref_time="010000", beg="20240310 060000", passive="OH.data")
+    tg.write_state_file(state, grid, imports, lats, lons)
+    r = tg.run_driver(REF_ORACLE, rundir, state, tmp_path / "reference.bin", 4)
+    assert r.returncode != 0
+    assert "OH_GridCompMod.F90 1872" in r.stdout and "Run phase 1 failed" in r.stdout
+    r = tg.run_driver(tg.DRIVER_ORACLE, rundir, state, tmp_path / "product.bin", 4)
+    assert r.returncode == 0, r.stdout[-3000:]
+    prod = tg.parse_output(tmp_path / "product.bin", grid, instances, [("OH_boost", False)])
+    assert len(prod) == 4
+    for t in prod:
+        assert np.array_equal(t["OH.data"]["OH"], clim)
+        assert t["OH"]["ran"] in (True, False)
 
 
 def test_reference_child_refuses_what_the_product_shell_refuses(tmp_path, small_model):
