@@ -211,6 +211,27 @@ def test_a_passive_data_instance_is_where_the_reference_child_stops_and_the_prod
         assert t["OH"]["ran"] in (True, False)
 
 
+def test_two_active_instances_reference_child_against_product_shell(tmp_path, small_model):
+    """ACTIVE_INSTANCES_OH: OH.1 OH.2 (QuickChem_GridComp.rc:22).  In the reference the booster handle and its first_time
+    flag are SAVE variables of predict_OH_with_XGB (:182,209): two instances in one process share one booster, loaded by
+    whichever ticks first.  The product's host keeps boosters by file name; with the same file the effect is the same.
+    Both instances, every tick, every export, reference child against product shell."""
+    instances = [("OH.1", False), ("OH.2", False)]
+    out, *_ = run_both(tmp_path, small_model, REF_ORACLE, tg.DRIVER_ORACLE, grid=(4, 3, 20), source="ONLINE_INST", nticks=6,
+                       seed=13, instances=instances, once_per_day=False, spinup=False, run_dt=1800, oh_dt=3600,
+                       avg24_tick=-1, ohscale=0.9, ref_time="000000", beg="20240131 220000", active="OH.1 OH.2")
+    (ref, _), (prod, _) = out["reference"], out["product"]
+    assert len(ref) == len(prod) == 6
+    boosts = 0
+    for a, b in zip(ref, prod):
+        for inst, _ in instances:
+            boosts += b[inst]["boosted"]
+            for name in ["OH"] + [e for e, _ in EXPORTS]:
+                assert np.array_equal(helpers.bits(a[inst][name]), helpers.bits(b[inst][name])), (a["tick"], inst, name)
+        assert np.array_equal(helpers.bits(b["OH.1"]["OH"]), helpers.bits(b["OH.2"]["OH"]))
+    assert boosts == 12            # (AGCM.rc holds OH_DT, not OH.1_DT / OH.2_DT: either instance's alarm falls back to RUN_DT)
+
+
 def test_reference_child_refuses_what_the_product_shell_refuses(tmp_path, small_model):
     """The error behaviour of the two children on the same bad inputs: an unknown OH_data_source, a
     wavelength GOCART2G does not have, a tropopause at or below 40 hPa with the static k range, a missing model file."""
