@@ -1,6 +1,7 @@
 """the steps either side of the predict call (feature engineering, k-slab,
 tropopause mask, unit conversion) as one device-resident pass, OHXBoosterRun1."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -440,3 +441,39 @@ def test_two_oh_instances_tick_from_two_threads(small_model, deep_model):
         jobs[0][0].set_param("ohx_register_host", "0")
         capi.check(jobs[0][0].lib, jobs[0][0].lib.OHXReleaseScratch())
     assert errors == []
+
+
+KNOB_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from quickchem_amd import capi, synth
+from tests import helpers
+model = synth.make_model(num_trees=20, max_depth=10, sample_log2=15, min_leaf=4, grid=synth.GRIDS["C12"])
+b = capi.Booster(model_buffer=model.image)
+st = helpers.run1_state((37, 11, 40), seed=3)
+call = b.run1_prepare(st, dynamic_k_range=True, want_boost=True, want_ndwet=True, want_diag=True)
+plain = {k: v.copy() for k, v in b.run1_call(call).items() if isinstance(v, np.ndarray)}
+b.set_param("ohx_register_host", "1")
+for tick in range(4):
+    got = b.run1_call(call)
+    for k, v in plain.items():
+        assert np.array_equal(got[k].view(np.uint32), v.view(np.uint32)), (tick, k)
+b.set_param("ohx_register_host", "0")
+print("KNOBS_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_the_host_tick_under_each_of_its_experiment_knobs():
+    """The knobs of the host form's tick (include/ohxgb.h part 3; each read once per process, hence a child per setting):
+    whatever order the lists cross in, whoever waits for them and however they are moved, a registered tick gives what a
+    pageable one gives, bit for bit."""
+    import subprocess
+    import sys
+    for env in ({"OHX_RUN1_GATE": "1"}, {"OHX_RUN1_SLAB_IN_PLACE": "1"}, {"OHX_RUN1_GATE": "1", "OHX_RUN1_SLAB_IN_PLACE": "1"},
+                {"OHX_RUN1_STREAMS": "1"}, {"OHX_COPY_POST_BLOCKS": "0"}, {"OHX_COPY_POST_BLOCKS": "8", "OHX_COPY_BACK_BLOCKS": "0"},
+                {"OHX_RUN1_STREAMS": "1", "OHX_RUN1_SLAB_IN_PLACE": "1", "OHX_COPY_BACK_BLOCKS": "32"}):
+        r = subprocess.run([sys.executable, "-c", KNOB_CHILD, helpers.ROOT], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=600, cwd=helpers.ROOT)
+        assert r.returncode == 0 and "KNOBS_OK" in r.stdout, (env, r.stdout[-1500:], r.stderr[-3000:])
