@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="cpu_baseline leg: 0 = skip, < 10 = a one-level sample, else the fixed sample (8 levels, 3 ticks)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_inclusive measurement (host-pointer entry points)")
+    ap.add_argument("--no-rank-ticks", action="store_true",
+                    help="skip the GEOS-rank tick measurement (the shell's Boost tick and skip tick as child processes)")
     ap.add_argument("--shuffle", action="store_true", help="permute the rows (destroys spatial coherence)")
     ap.add_argument("--infer-grid", action="store_true",
                     help="rows path: no hint either, but let the library look for the level size in the rows "
@@ -374,6 +376,29 @@ def run1_host(booster):
     return out
 
 
+def rank_ticks():
+    """What a GEOS rank pays per OH tick under the reference's shipped compute_once_per_day: T (OH_instance_OH.rc:38):
+    one Boost tick a model day and 23 ticks that skip it (OH_GridCompMod.F90:1189-1193, 1247-1257, 1579-1595), through
+    the product's shell (quickchem_amd/fortran/oh_gridcomp.F90 under the mock GEOS cap) and through the reference's own
+    child compiled in place (its xgboost calls served by libohxgb.so; present only where oracle/_ref was built), one
+    rank alone and six sharing the GPU, a 48 x 24 x 72 block each.  Child processes only, started BEFORE this process
+    opens the GPU (the box admits six processes on a card).  tools/rank_tick_end_to_end.py; never `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import rank_tick_end_to_end as rt
+        rec = rt.measure(ranks=(1, 6), days=1, once=True, arms=("reference_child", "product_shell"))
+    except Exception as exc:                      # an extra, not the headline: say so and go on
+        return {"error": f"{type(exc).__name__}: {exc}"[:400]}
+    brief = lambda q: None if q is None else {k: round(q[k], 1) for k in ("median", "p90", "p99", "max")} | {"n": q["n"]}
+    out = {"block": rec["block"], "what": rec["what"], "booster": rec["booster"], "model_days": rec["model_days"], "ranks": {}}
+    for P, arms in rec["ranks"].items():
+        out["ranks"][P] = {tag: {"boost_tick_us": brief(a["boost_tick_us"]), "skip_tick_us": brief(a["skip_tick_us"]),
+                                 "model_day_us": a["model_day_us_median_ticks"]} for tag, a in arms.items() if tag != "check"}
+    if "reference_child" in rec:
+        out["reference_child"] = rec["reference_child"]
+    return out
+
+
 def bench_run1(args, grid, n_total, model, booster, dev, t_model):
     """OH Run1 from the imports to INTERNAL OH, everything resident in HBM."""
     import ctypes as C
@@ -628,6 +653,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world} (start `python bench.py --gpus N` plainly, or under "
                          f"python -m torch.distributed.run --nproc-per-node N)")
+    # the GEOS-rank ticks run as child processes and must be over before this process opens the GPU
+    shell_ticks = None
+    if (world == 1 and args.path == "rows" and not args.no_rank_ticks and not args.no_pcie and args.cpu_seconds > 0
+            and not args.shuffle and not args.missing_ppm and not args.rows and not args.param
+            and (args.trees, args.depth, args.grid) == (100, 18, "C360")):
+        shell_ticks = rank_ticks()
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     # rehearsal of the multi-rank path on a one-GPU box: OHX_BENCH_SHARE_GPU=1 puts every rank on device 0
     # (RCCL refuses two ranks on one device, so OHX_BENCH_BACKEND=gloo goes with it); never for numbers
@@ -936,6 +967,7 @@ def main():
             "cpu_baseline": cpu,
             "pcie_inclusive": pcie,
             "run1_host": host_tick,
+            "rank_ticks": shell_ticks,
         }
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:

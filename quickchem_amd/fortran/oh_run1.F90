@@ -12,7 +12,7 @@ module oh_run1
    private
 
    public :: OH_RUN1_STATE, OH_RUN1_DIAG, oh_run1_boost, oh_post_process, oh_solar_geometry, oh_julian_day
-   public :: oh_solar_geometry_host
+   public :: oh_solar_geometry_host, oh_post_process_host
    public :: oh_run1_error_text, oh_run1_register_host_arrays
 
    !  struct OHXRun1Args, member for member
@@ -327,6 +327,36 @@ contains
          last_error = 'Failed in OHXOHPostProcess :: '//ohx_last_error()
          rc = OH_XGB_FAILURE
       end if
+   end subroutine
+
+   !  The same tick on the rank's own core - the tick OH_instance_OH.rc:38 (compute_once_per_day: T) makes 23 times out
+   !  of 24: OH_ML is the last Boost's, nothing on it needs a tree.  One pass, each gridcell read once and written once,
+   !  with the reference's expressions in the reference's order of operations (default REAL throughout):
+   !    PL = (PLE(k-1) + PLE(k)) * 0.5, TV = T * (1 + Q/eps) / (1 + Q), NDWET = (AVOGAD*PL) / (RUNIV*TV)     :1247-1257
+   !    OH = OH_ML where PL > TROPP, default_OH elsewhere                                                      :1579-1587
+   !    OH = (OH * NDWET) * 1.0e-6                                                                             :1595
+   !  The reference makes four whole-array passes with three temporaries allocated per tick (:1240-1242); the results
+   !  are the same bits (tests/test_reference_child.py, every skip tick of the two model days).
+   subroutine oh_post_process_host(im, jm, km, avogad, runiv, epsilon, PLE_MOD, T_MOD, Q_MOD, TROPP_MOD, default_OH, &
+                                   OH_ML, OH, NDWET)
+      integer, intent(in) :: im, jm, km
+      real, intent(in)  :: avogad, runiv, epsilon
+      real, intent(in)  :: PLE_MOD(im, jm, 0:km), T_MOD(im, jm, km), Q_MOD(im, jm, km), TROPP_MOD(im, jm)
+      real, intent(in)  :: default_OH(im, jm, km), OH_ML(im, jm, km)
+      real, intent(out) :: OH(im, jm, km), NDWET(im, jm, km)
+      real :: pl, tv, nd
+      integer :: i, j, k
+      do k = 1, km
+         do j = 1, jm
+            do i = 1, im
+               pl = (PLE_MOD(i,j,k-1) + PLE_MOD(i,j,k)) * 0.5
+               tv = T_MOD(i,j,k) * (1.0 + Q_MOD(i,j,k) / epsilon) / (1.0 + Q_MOD(i,j,k))
+               nd = (avogad * pl) / (runiv * tv)
+               NDWET(i,j,k) = nd
+               OH(i,j,k) = (merge(OH_ML(i,j,k), default_OH(i,j,k), pl > TROPP_MOD(i,j)) * nd) * 1.0e-6
+            end do
+         end do
+      end do
    end subroutine
 
 end module oh_run1

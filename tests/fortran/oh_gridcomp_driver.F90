@@ -184,7 +184,7 @@ program oh_gridcomp_driver
    ninst = size(gcs)
    open(newunit=uo, file=trim(out_file), access='stream', form='unformatted', status='replace', action='write')
    write(uo) int(nticks, c_int32_t), int(ninst, c_int32_t), int(nwant, c_int32_t)
-   !  OHX_DRIVER_TIMING in the environment: the wall time of every tick's two run phases on stdout, "TICK_US <tick> <us>"
+   !  OHX_DRIVER_TIMING in the environment: the wall time of every tick's two run phases on stdout, "TICK_US <tick> <us> <nhms>"
    call get_environment_variable('OHX_DRIVER_TIMING', timing)
    !  OHX_DRIVER_MEET_AT=<seconds of the day, UTC>: after tick 0 (which loads the model) wait for that time - several
    !  drivers started together then tick together, as the ranks of a model do
@@ -201,11 +201,11 @@ program oh_gridcomp_driver
       call ESMF_GridCompRun(root, clock=clock, phase=2, rc=rc)
       if (rc /= ESMF_SUCCESS) call die('Run phase 2 failed')
       call system_clock(clock1)
-      if (len_trim(timing) > 0) print '(a,i0,1x,f0.1)', 'TICK_US ', tick, real(clock1 - clock0, 8) * 1.0d6 / real(clock_rate, 8)
       call ESMF_ClockGet(clock, currTime=now)
       call ESMF_TimeGet(now, YY=yy, MM=mm, DD=dd, H=h, M=m, S=s)
       call MAPL_PackTime(nymd, yy, mm, dd)
       call MAPL_PackTime(nhms, h, m, s)
+      if (len_trim(timing) > 0) print '(a,i0,1x,f0.1,1x,i0)', 'TICK_US ', tick, real(clock1 - clock0, 8) * 1.0d6 / real(clock_rate, 8), nhms
       write(uo) int(tick, c_int32_t), int(nymd, c_int32_t), int(nhms, c_int32_t)
       do c = 1, size(gcs)
          call MAPL_GetObjectFromGC(gcs(c), cmeta, rc)

@@ -104,7 +104,7 @@ def write_state_file(path, grid, imports, lats, lons):
 
 def write_rundir(d, *, source, model_pattern, once_per_day=True, spinup=True, policy="reference", run_dt=1800,
                  oh_dt=3600, ref_time="003000", beg="20240131 000000", exports=(), avg24_tick=-1,
-                 active="OH", passive="", ohscale=0.85, wavelength=550, register=False):
+                 active="OH", passive="", ohscale=0.85, wavelength=550, register=False, skip_tick=None):
     os.makedirs(d, exist_ok=True)
     open(os.path.join(d, "AGCM.rc"), "w").write(
         f"# mock of the GEOS AGCM.rc keys OH reads\nRUN_DT: {run_dt}\nQUICKCHEM_DT: {run_dt}\nOH_DT: {oh_dt}\n"
@@ -116,7 +116,8 @@ def write_rundir(d, *, source, model_pattern, once_per_day=True, spinup=True, po
     open(os.path.join(d, "OH_instance_OH.rc"), "w").write(
         f"nbins: 1\nXGBoostFile: {model_pattern}\nOH_data_source: {source}\nspinup_24hr_imports: {'T' if spinup else 'F'}\n"
         f"wavelength_for_scacoef: {wavelength}\ncompute_once_per_day: {'T' if once_per_day else 'F'}\nOHscale: {ohscale}\n"
-        f"XGBoost_model_policy: {policy}\n" + ("register_host_arrays: T\n" if register else ""))
+        f"XGBoost_model_policy: {policy}\n" + ("register_host_arrays: T\n" if register else "")
+        + (f"skip_tick: {skip_tick}\n" if skip_tick else ""))
 
 
 def run_driver(exe, rundir, state, out, nticks):

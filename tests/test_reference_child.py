@@ -19,7 +19,6 @@ What this does NOT do: pin xgboost.  Under both children the trees are walked by
 reference holds no xgboost arithmetic.  PARITY WITH libxgboost 1.6.0 STAYS UNPINNED.
 
 Skipped where oracle/_ref/refchild is not built (no /root/reference and no prebuilt files)."""
-import json
 import os
 
 import numpy as np
@@ -102,13 +101,16 @@ def compare(ref_ticks, prod_ticks, tolerance=None, exports=None):
     return boosts
 
 
-def test_two_model_days_reference_child_against_product_shell_on_the_cpu(tmp_path, small_model):
+@pytest.mark.parametrize("skip_tick", [None, "device"])
+def test_two_model_days_reference_child_against_product_shell_on_the_cpu(tmp_path, small_model, skip_tick):
     """BASELINE config #1's two model days (half-hour heartbeat, OH_DT one hour, ONLINE_AVG24 with spin-up,
     compute_once_per_day -> static k range, daily means arriving at tick 40, January -> February): every tick's INTERNAL
-    OH and all thirty exports of the reference's own child and of the product's shell, both over the oracle: bit for bit."""
+    OH and all thirty exports of the reference's own child and of the product's shell, both over the oracle: bit for bit.
+    46 of the 49 OH ticks skip Boost (:1189-1193): the shell's fused host pass (skip_tick: host, the default) and its
+    OHXOHPostProcess call (skip_tick: device; here the oracle's) against the reference's :1247-1257,1579-1595."""
     out, *_ = run_both(tmp_path, small_model, REF_ORACLE, tg.DRIVER_ORACLE, grid=(5, 4, 24), source="ONLINE_AVG24",
                        nticks=98, once_per_day=True, spinup=True, run_dt=1800, oh_dt=3600, avg24_tick=40, ohscale=0.85,
-                       ref_time="003000", beg="20240131 000000")
+                       ref_time="003000", beg="20240131 000000", skip_tick=skip_tick)
     (ref, ref_log), (prod, prod_log) = out["reference"], out["product"]
     assert compare(ref, prod) == 3                                                # Boost at ticks 0, 48, 96
     for log in (ref_log, prod_log):
@@ -277,14 +279,18 @@ def test_reference_child_drives_the_gpu_through_the_c_abi(tmp_path, small_model)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["two_days_avg24", "precomputed_dynamic", "online_inst_dynamic"])
+@pytest.mark.parametrize("case", ["two_days_avg24", "two_days_avg24_skip_tick_on_device", "precomputed_dynamic",
+                                  "online_inst_dynamic"])
 def test_product_shell_on_the_gpu_against_the_reference_child(tmp_path, small_model, case):
     """The product's shell on the MI355X (OHXBoosterRun1: feature kernels, k-slab, fused walk, mask, conversion) against
     the reference's own child on the same state: engineered features, NDWET, SZA and every other DIAG export bit for bit;
-    OH_boost within 2 ulp and INTERNAL OH within 3 (the fused kernel's 10**x against the host's)."""
-    if case == "two_days_avg24":
+    OH_boost within 2 ulp and INTERNAL OH within 3 (the fused kernel's 10**x against the host's).  The two-day case has
+    46 ticks that skip Boost: by default the shell does those on the rank's core (skip_tick: host, oh_post_process_host),
+    in the second parametrisation through OHXOHPostProcess on the GPU."""
+    if case.startswith("two_days_avg24"):
         kw = dict(grid=(5, 4, 24), source="ONLINE_AVG24", nticks=98, once_per_day=True, spinup=True, run_dt=1800,
-                  oh_dt=3600, avg24_tick=40, ohscale=0.85, ref_time="003000", beg="20240131 000000", register=True)
+                  oh_dt=3600, avg24_tick=40, ohscale=0.85, ref_time="003000", beg="20240131 000000", register=True,
+                  skip_tick="device" if case.endswith("device") else None)
         boosts = 3
     else:
         kw = dict(grid=(6, 5, 30), source="PRECOMPUTED" if case.startswith("pre") else "ONLINE_INST", nticks=8, seed=11,
@@ -318,58 +324,29 @@ def test_reference_child_and_product_shell_on_a_block_the_ring_kernels_take(tmp_
     assert np.count_nonzero(prod[0]["OH"]["OH_boost"]) > 200_000
 
 
-def tick_times_us(stdout):
-    return [float(ln.split()[2]) for ln in stdout.splitlines() if ln.startswith("TICK_US ")]
-
-
 @pytest.mark.gpu
-def test_a_rank_s_oh_tick_end_to_end_reference_child_and_product_shell(tmp_path, deep_model, monkeypatch):
-    """What switching buys a GEOS rank, measured where the rank sees it: the wall time of Run1 + Run2 of one OH tick on a
-    48 x 24 x 72 block (NOTES.wiki's rank size), every tick a Boost tick, HISTORY asking for no DIAG export.
-      reference child: the reference's own OH_GridCompMod.F90 - feature engineering (:1444-1482, the O(km^2) column sums), the
-        gather (:308-345), 10**x, mask and conversion on the rank's core; the five xgboost calls into libohxgb.so on the GPU
-      product shell:   quickchem_amd/fortran/oh_gridcomp.F90 - one OHXBoosterRun1 per tick, arrays registered
-    Same parent, same state file, same model, same GPU; the two runs agree as the smaller cases above do.  The numbers go
-    to gpurun_out/ (profiles/r05_rank_tick_end_to_end.json is a copy); the assertion is only that the product's tick is
-    the shorter one."""
-    monkeypatch.setenv("OHX_DRIVER_TIMING", "1")
-    grid = (48, 24, 72)
-    kw = dict(grid=grid, source="ONLINE_INST", nticks=40, seed=21, once_per_day=False, spinup=False, run_dt=1800,
-              oh_dt=1800, avg24_tick=-1, ohscale=0.85, ref_time="000000", beg="20240131 000000", exports=[])
+def test_a_rank_s_oh_tick_end_to_end_reference_child_and_product_shell(tmp_path, deep_model):
+    """A GEOS rank's block (48 x 24 x 72, NOTES.wiki's rank size) with HISTORY asking for no DIAG export, the way
+    tools/rank_tick_end_to_end.py times it: the reference's own child (its five xgboost calls into libohxgb.so) and the
+    product's shell (one OHXBoosterRun1 per Boost tick, arrays registered; the fused host pass on the ticks that skip
+    Boost) over one model day and an hour of hourly ticks under compute_once_per_day - 2 Boost ticks, 23 that skip it.
+    INTERNAL OH of every tick within the 10**x tolerance.  No duration is asserted here: the clock belongs to the tool."""
+    kw = dict(grid=(48, 24, 72), source="ONLINE_INST", nticks=26, seed=21, once_per_day=True, spinup=False, run_dt=3600,
+              oh_dt=3600, avg24_tick=-1, ohscale=0.85, ref_time="000000", beg="20240131 000000", exports=[])
     out, *_ = run_both(tmp_path, deep_model, REF_HIP, tg.DRIVER_HIP, **kw)
-    (ref, ref_log), (prod, prod_log) = out["reference"], out["product"]
-    assert compare(ref, prod, tolerance=POW10, exports=[]) == 40
-    t_ref, t_prod = tick_times_us(ref_log)[5:], tick_times_us(prod_log)[5:]
-    assert len(t_ref) == len(t_prod) == 35
-    med = lambda xs: float(np.median(xs))
-    record = {"block": list(grid), "ticks_timed": 35, "data_source": "ONLINE_INST", "booster": "100 trees, depth <= 18 (synthetic)",
-              "slab_levels": [int(prod[-1]["OH"]["k1"]), int(prod[-1]["OH"]["k2"])],
-              "reference_child_tick_us": {"median": med(t_ref), "min": min(t_ref), "max": max(t_ref)},
-              "product_shell_tick_us": {"median": med(t_prod), "min": min(t_prod), "max": max(t_prod)},
-              "what": "wall time of ESMF_GridCompRun phase 1 + 2 of the parent per tick, one rank alone on the GPU; reference child = "
-                      "OH_GridCompMod.F90 compiled in place, its five xgboost calls served by libohxgb.so"}
-    print("RANK_TICK " + json.dumps(record))
-    outdir = os.path.join(helpers.ROOT, "gpurun_out")
-    if os.path.isdir(outdir) and os.access(outdir, os.W_OK):
-        json.dump(record, open(os.path.join(outdir, "rank_tick_end_to_end.json"), "w"), indent=1)
-    assert med(t_prod) < med(t_ref)
+    (ref, _), (prod, _) = out["reference"], out["product"]
+    assert compare(ref, prod, tolerance=POW10, exports=[]) == 2
+    assert [t["tick"] for t in prod if t["OH"]["boosted"]] == [0, 24]
 
 
 @pytest.mark.gpu
-def test_several_ranks_on_the_gpu_end_to_end_reference_child_and_product_shell(tmp_path, deep_model, monkeypatch):
-    """The same measurement the way a GEOS node runs: several ranks, each a process with a 48 x 24 x 72 block of its own,
-    sharing the one GPU (NOTES.wiki:14,33: a rank per core).  P copies of the reference child's driver, then P of the
-    product shell's, started together and held at a common time after their first tick; every later tick of every rank
-    is timed (wall time of the parent's two run phases).  Written to gpurun_out/; asserted: the product's median tick is the
-    shorter.  P = 4 here: the GPU boxes admit six processes on the card, the test runner - which has run GPU tests of
-    its own by now - is one of them, and one is left as a margin.  OHX_E2E_RANKS=5 fits inside the suite as well
-    (profiles/r05_five_ranks_end_to_end.json); 6 only for a run of this test ALONE (pytest -k several_ranks: the runner
-    then never opens the GPU) - profiles/r05_six_ranks_end_to_end.json was made that way."""
+def test_two_ranks_on_the_gpu_reference_child_and_product_shell(tmp_path, deep_model):
+    """Two ranks - two processes, each with a 48 x 24 x 72 block - sharing the one GPU (NOTES.wiki:14,33: a rank per core;
+    tools/rank_tick_end_to_end.py runs up to six and keeps the clock): both ranks of the reference child and both of the
+    product shell, started together, give what a rank alone gives - the library's streams, its registered arrays and its
+    ring kernel are per process and do not see each other."""
     import subprocess
-    import time
-    monkeypatch.setenv("OHX_DRIVER_TIMING", "1")
-    grid, nticks, P = (48, 24, 72), 60, int(os.environ.get("OHX_E2E_RANKS", "4"))
-    assert 1 <= P <= 6
+    grid, nticks, P = (48, 24, 72), 6, 2
     imports, lats, lons = tg.mock_imports(grid, "ONLINE_INST", seed=21)
     (tmp_path / "oh_M01.model").write_bytes(deep_model.image.tobytes())
     rundir, state = tmp_path / "run", tmp_path / "state.bin"
@@ -377,29 +354,15 @@ def test_several_ranks_on_the_gpu_end_to_end_reference_child_and_product_shell(t
                     once_per_day=False, spinup=False, run_dt=1800, oh_dt=1800, avg24_tick=-1, ohscale=0.85,
                     ref_time="000000", beg="20240131 000000")
     tg.write_state_file(state, grid, imports, lats, lons)
-    record = {"block": list(grid), "ranks": P, "ticks_per_rank": nticks - 1, "data_source": "ONLINE_INST",
-              "what": "that many driver processes on one GPU, ticking together from their second tick on; per-tick wall time of the "
-                      "parent's two run phases over all ranks, us"}
-    medians = {}
+    ticks = {}
     for tag, exe in (("reference_child", REF_HIP), ("product_shell", tg.DRIVER_HIP)):
-        now = time.gmtime(time.time() + 12.0)
-        env = dict(os.environ, OHX_DRIVER_MEET_AT=str(now.tm_hour * 3600 + now.tm_min * 60 + now.tm_sec))
-        procs = [subprocess.Popen([exe, str(rundir), str(state), str(tmp_path / f"{tag}_{r}.bin"), str(nticks)], env=env,
+        procs = [subprocess.Popen([exe, str(rundir), str(state), str(tmp_path / f"{tag}_{r}.bin"), str(nticks)],
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(P)]
-        ticks = []
         for p in procs:
             out, _ = p.communicate(timeout=600)
             assert p.returncode == 0, (tag, out[-2000:])
-            ticks += tick_times_us(out)[1:]
-        for r in range(P):
-            os.remove(tmp_path / f"{tag}_{r}.bin")
-        assert len(ticks) == P * (nticks - 1)
-        ticks.sort()
-        medians[tag] = ticks[len(ticks) // 2]
-        record[tag + "_tick_us"] = {"median": medians[tag], "p10": ticks[len(ticks) // 10], "p90": ticks[len(ticks) * 9 // 10],
-                                    "p99": ticks[len(ticks) * 99 // 100], "max": ticks[-1], "mean": sum(ticks) / len(ticks)}
-    print("RANKS_END_TO_END " + json.dumps(record))
-    outdir = os.path.join(helpers.ROOT, "gpurun_out")
-    if os.path.isdir(outdir) and os.access(outdir, os.W_OK):
-        json.dump(record, open(os.path.join(outdir, "ranks_end_to_end_%d.json" % P), "w"), indent=1)
-    assert medians["product_shell"] < medians["reference_child"]
+        ranks = [tg.parse_output(tmp_path / f"{tag}_{r}.bin", grid, [("OH", False)], []) for r in range(P)]
+        for a, b in zip(*ranks):                                       # the same state on both ranks: the same bits
+            assert np.array_equal(helpers.bits(a["OH"]["OH"]), helpers.bits(b["OH"]["OH"])), (tag, a["tick"])
+        ticks[tag] = ranks[0]
+    assert compare(ticks["reference_child"], ticks["product_shell"], tolerance=POW10, exports=[]) == nticks
