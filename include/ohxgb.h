@@ -104,9 +104,9 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *   "ohx_reserve_cus" ring kernels (rows): compute units left free, 0..128 (default 0).  A ring block owns its CU for the
  *                     length of a launch; a collective enqueued beside the predict (OHXAllGatherOH, torch.distributed)
  *                     otherwise only gets on the chip at a launch boundary
- *   "ohx_run1_pieces" OHXBoosterRun1[Device] on a slab of several launches of the ring kernel: ranges of j walked one after
- *                     the other, with the feature engineering of the next and the post-processing of the last on a
- *                     second stream beside the walk; 0 = as many as pay (default), 1 = one piece, n = n pieces
+ *   "ohx_run1_pieces" experiment knob of OHXBoosterRun1[Device]: n > 1 walks n ranges of j one after the other, with the
+ *                     feature engineering of the next and the post-processing of the last on a second stream beside
+ *                     the walk; 0 and 1 = one piece (default: measured, pieces are slower - profiles/r05_sweeps.txt)
  *   "ohx_register_host"  0 | 1, process-wide (the handle may be NULL): the host arrays handed to OHXBoosterRun1,
  *                     OHXOHPostProcess and OHXBoosterPredictFields are registered with the GPU driver the first time
  *                     they are seen and moved by DMA - a rank-sized block's forty arrays by ONE copy launch - from
@@ -153,7 +153,13 @@ int OHXDeviceCount(int* out);
 /* As XGDMatrixCreateFromMat, but `d_data` already lives in HBM.  The matrix
  * BORROWS the pointer (no copy); it must stay valid until XGDMatrixFree.
  * The inf check of the host path is folded into the predict kernels instead:
- * a predict on data holding +-inf fails (OHXBoosterCheck reports it). */
+ * a predict on data holding +-inf fails (OHXBoosterCheck reports it).
+ * Ordering: the library reads the rows on streams of its own.  The host-form
+ * calls on such a matrix (XGBoosterPredict, XGDMatrixSaveBinary) first wait for
+ * everything enqueued so far on the legacy default stream, hence on every
+ * blocking stream; rows filled on a NON-blocking stream of the caller's must
+ * be synchronised by the caller, or the *Device forms used, which take the
+ * producing stream as an argument. */
 int OHXDMatrixCreateFromDevice(const float* d_data, bst_ulong nrow, bst_ulong ncol, float missing, DMatrixHandle* out);
 
 /* Optional hint, any DMatrix: its rows are rows row0, row0+1, ... of the gather

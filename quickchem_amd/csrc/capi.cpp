@@ -125,6 +125,7 @@ DeviceInfo use_device(int ordinal) {
 // hundred took 14-37 ms instead of 1; with two each, none did (profiles/r05_sweeps.txt, "six ranks").
 struct LibStreams {
   hipStream_t exec = nullptr, copy = nullptr;
+  hipEvent_t caller = nullptr;      // order_behind_caller
 };
 LibStreams& lib_streams(int ordinal) {
   static std::mutex mu;
@@ -140,6 +141,18 @@ LibStreams& lib_streams(int ordinal) {
     if (cur != ordinal) HIP_CHECK(hipSetDevice(cur));
   }
   return ls;
+}
+// A host-form call on a matrix that BORROWS the caller's HBM (OHXDMatrixCreateFromDevice): whatever the caller has
+// enqueued on the legacy default stream - and so on every blocking stream, torch's default among them - to fill those
+// rows must be there before the library's non-blocking stream reads them.  The null-stream launch these calls made
+// until round 4 gave that order by itself.  An event on the default stream, waited for by `s`; nothing of
+// the library runs on the default stream.  A producer on a NON-blocking stream of the caller's is the caller's to
+// synchronise (include/ohxgb.h), or to name: the *Device forms take the stream.
+void order_behind_caller(int ordinal, hipStream_t s) {
+  LibStreams& ls = lib_streams(ordinal);
+  if (ls.caller == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ls.caller, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(ls.caller, nullptr));
+  HIP_CHECK(hipStreamWaitEvent(s, ls.caller, 0));
 }
 // the current device's
 hipStream_t exec_stream() {
@@ -479,7 +492,7 @@ struct DMatrixObj {
 
 struct BoosterObj {
   ~BoosterObj() {
-    for (hipEvent_t e : {run1_fork, run1_slab, run1_join})
+    for (hipEvent_t e : {run1_fork, run1_slab, run1_join, run1_clear})
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : run1_prep) (void)hipEventDestroy(e);
     for (hipEvent_t e : run1_walk) (void)hipEventDestroy(e);
@@ -532,7 +545,7 @@ struct BoosterObj {
   // fused calls: PCIe copies on s_copy beside the kernels on s_exec.  OH Run1's device form: the slab count, and the
   // streaming kernels of the pieces that are not being walked, on s_copy beside the caller's stream
   hipStream_t s_copy = nullptr, s_exec = nullptr;
-  hipEvent_t run1_fork = nullptr, run1_slab = nullptr, run1_join = nullptr;
+  hipEvent_t run1_fork = nullptr, run1_slab = nullptr, run1_join = nullptr, run1_clear = nullptr;
   std::vector<hipEvent_t> run1_prep, run1_walk, run1_feed_events;
   PinnedBuf<int32_t> h_slab;
   std::vector<DevBuf<float>> d_stage;  // fused host path: per-field staging
@@ -540,7 +553,8 @@ struct BoosterObj {
   // Run1: engineered features, OH_ML and the slab result stay in HBM between the steps
   DevBuf<float> d_run1[10];
   DevBuf<int32_t> d_slab;
-  bool slab_zeroed = false;            // d_slab's two words are zero whenever no slab count is enqueued (run1_device)
+  bool slab_zeroed = false;            // d_slab's two words are zero whenever no slab count is enqueued (run1_device) ...
+  hipStream_t slab_zeroed_on = nullptr; // ... by a memset on this stream, with run1_clear recorded behind it
   // clustering pass for rows in no known order (kernels.hip)
   DevBuf<uint32_t> d_cluster_keys[2], d_cluster_vals[2], d_cluster_small;
   DevBuf<uint8_t> d_cluster_temp;
@@ -961,7 +975,11 @@ const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a,
 // `im`, `jm`, `row0`: the grid the rows come from (0 = unknown): the buffer is sized for the tiles the launcher will
 // really make of them - bricks over the rows' levels, or 64 consecutive rows where bricks would be mostly empty -
 // not for a bound (a 48 x 24 x 72 rank block took 73 MB per booster; now 24 MB).
-void leaf_room(BoosterObj& b, uint64_t nrow, uint32_t ntree, LaunchTuning& tune, int im, int jm, uint64_t row0) {
+// `plan_only` (OHXBoosterKernelSymbolRows, a query): what a predict of this batch WOULD be handed - the buffer as it is or
+// as it would be made - without making it: the launch planner only looks at the pointer being non-NULL and at the size.
+float* const kPlannedBuffer = reinterpret_cast<float*>((uintptr_t)256);
+void leaf_room(BoosterObj& b, uint64_t nrow, uint32_t ntree, LaunchTuning& tune, int im, int jm, uint64_t row0,
+               bool plan_only = false) {
   if (tune.tree_split == 0 || !b.super_ok || nrow == 0 || nrow > (uint64_t)b.dev.num_cus * 10u * 64u + 4096u) return;
   size_t tiles = (size_t)((nrow + 63) / 64);
   if (im > 0 && jm > 0) {
@@ -971,9 +989,24 @@ void leaf_room(BoosterObj& b, uint64_t nrow, uint32_t ntree, LaunchTuning& tune,
       probe.set_grid((uint32_t)im, (uint32_t)jm, row0, nrow, (uint32_t)tune.brick_li, (uint32_t)tune.brick_lj, (uint32_t)tune.brick_lk);
     if (probe.im != 0 && probe.ntiles(nrow) > tiles) tiles = (size_t)probe.ntiles(nrow);
   }
+  if (plan_only) {
+    tune.leaf_buf = b.d_leaves.p != nullptr ? b.d_leaves.p : kPlannedBuffer;
+    tune.leaf_words = std::max(b.d_leaves.n, tiles * 64 * (size_t)ntree);
+    return;
+  }
   b.d_leaves.ensure(tiles * 64 * (size_t)ntree);
   tune.leaf_buf = b.d_leaves.p;
   tune.leaf_words = b.d_leaves.n;
+}
+
+// What defer_prepare would say and hand out for this batch, touching nothing: not the pending read-back, not
+// defer_too_many, no allocation, no memset on any stream (the query used to do all four, the memset on NULL).
+bool defer_plan(const BoosterObj& b, uint64_t nrow, LaunchTuning& tune) {
+  if (tune.defer_missing == 0 || !(tune.defer_missing > 0 || nrow >= (1u << 18))) return false;
+  tune.defer_buf = b.d_defer.p != nullptr ? b.d_defer.p : reinterpret_cast<uint32_t*>(kPlannedBuffer);
+  tune.defer_words = std::max(b.d_defer.n, (size_t)(nrow / 32 + 1024 + 1));
+  tune.defer_count_only = (b.defer_too_many && tune.defer_missing < 0) ? 1 : 0;
+  return true;
 }
 
 bool defer_prepare(BoosterObj& b, uint64_t nrow, LaunchTuning& tune, hipStream_t stream) {
@@ -1182,6 +1215,7 @@ int XGDMatrixSaveBinary(DMatrixHandle handle, const char* fname, int silent) {
   if (count) {
     HIP_CHECK(hipSetDevice(d->device));
     hipStream_t st = lib_streams(d->device).exec;
+    if (d->owned == nullptr) order_behind_caller(d->device, st);
     HIP_CHECK(hipMemcpyAsync(host.data(), d->d_data, count * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
   }
@@ -1378,7 +1412,7 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
     g_copy_blocks.store((uint32_t)std::max(0, atoi(value)));
   } else if (n == "ohx_run1_pieces") {
     const int k = atoi(value);
-    if (k < 0 || k > 64) throw OhxError("ohx_run1_pieces must be 0 (auto) .. 64");
+    if (k < 0 || k > 64) throw OhxError("ohx_run1_pieces must be 0 .. 64 (0 and 1: one piece)");
     b->tune.run1_pieces = k;
   } else if (n == "ohx_tree_split") {
     if (v == "auto") b->tune.tree_split = -1;
@@ -1433,6 +1467,7 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
   ensure_uploaded(*b);
   b->d_pred.ensure(count);
   b->h_pred.ensure(count);
+  if (d->owned == nullptr) order_behind_caller(b->dev.ordinal, b->s_exec);
   launch_predict_checked(*b, *d, option_mask, ntree_limit, b->d_pred.p, b->s_exec);
   if (count) HIP_CHECK(hipMemcpyAsync(b->h_pred.p, b->d_pred.p, count * sizeof(float), hipMemcpyDeviceToHost, b->s_exec));
   raise_flag_errors(*b, b->s_exec);              // waits for the stream: the predictions are in h_pred
@@ -1695,11 +1730,12 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   // column.  So of the streaming kernels (pointwise features, column sums, slab count, post-processing: 1.3 ms of a
   // C360 tick's 20.2 when they ran one after the other around the walk) only the first piece's features and the last
   // piece's post-processing are not hidden behind a walk, which leaves the CUs' spare registers and the whole of HBM's
-  // bandwidth to them.  A slab of fewer than two launches of the ring kernel (a rank's block) is one piece.
+  // bandwidth to them.  That was the plan; measured, pieces lose (below), so a tick is ONE piece unless ohx_run1_pieces > 1.
   if (!b.run1_fork) {
     HIP_CHECK(hipEventCreateWithFlags(&b.run1_fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&b.run1_slab, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&b.run1_join, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&b.run1_clear, hipEventDisableTiming));
   }
   b.h_slab.ensure(2);
   // The side stream.  Device form: the library's copy stream, idle there (the slab count runs beside the first
@@ -1729,10 +1765,17 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   }
   // (the result words are zero: set so when they were made, and again behind every read-back - a memset in front of the
   // count was a 12 us launch on the tick's critical path)
+  // That trailing memset went to the side stream of ITS tick, and the device form returns with it still pending.  A tick
+  // whose side stream is another one (device form, then host form; OHX_RUN1_STREAMS=1) must not count into words the old
+  // memset has yet to clear - slab = 0, k1 = km + 1, nothing predicted, silently: it waits for run1_clear,
+  // recorded behind that memset.
   if (!b.slab_zeroed) {
     HIP_CHECK(hipMemsetAsync(b.d_slab.p, 0, 2 * sizeof(int32_t), side));
     b.slab_zeroed = true;
+  } else if (b.slab_zeroed_on != side) {
+    HIP_CHECK(hipStreamWaitEvent(side, b.run1_clear, 0));
   }
+  b.slab_zeroed_on = side;
   HIP_CHECK(launch_k_slab(sa, side));
   // ... and the next list is handed to the copy stream before this thread turns to anything else: the calls that
   // enqueue the rest of the slab count took it 50 us, during which the link stood idle (profiles/r05_sweeps.txt)
@@ -1740,6 +1783,7 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   HIP_CHECK(hipMemcpyAsync(b.h_slab.p, b.d_slab.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, side));
   HIP_CHECK(hipEventRecord(b.run1_slab, side));
   HIP_CHECK(hipMemsetAsync(b.d_slab.p, 0, 2 * sizeof(int32_t), side));
+  HIP_CHECK(hipEventRecord(b.run1_clear, side));
   HIP_CHECK(hipMemsetAsync(oh_ml, 0, vol * sizeof(float), side));            // self%OH_ML(:,:,:) = 0.0 (:1559)
   // A kernel that needs a list of the feed waits for it in one of two ways.  Enqueued behind a wait on the list's event
   // (hipStreamWaitEvent: a barrier packet on this queue that the command processor re-examines at its leisure - the
@@ -1748,20 +1792,14 @@ static void run1_device(BoosterObj& b, const OHXRun1Args& r, hipStream_t stream,
   // difference - the barriers' delay lies under the link's time (OHXBoosterRun1 below) - so nothing is gated by default.
   if (prep_inputs != nullptr && !gated) HIP_CHECK(hipStreamWaitEvent(stream, prep_inputs, 0));
 
-  // pieces: as many as the slab's tiles make whole launches of the ring kernel (at its most, all km levels), of whole
-  // rows of bricks (four j); the pieces' extents do not depend on the slab count, which is not known yet
+  // pieces: ONE by default (ohx_run1_pieces 0 or 1).  n > 1 is an experiment knob: ranges of whole rows of bricks (four
+  // j) walked one after the other, the pieces' extents independent of the slab count, which is not known yet.  Measured
+  // (profiles/r05_sweeps.txt): more than one piece is slower - predict_fields_ring_kernel takes all of a CU's vector
+  // registers (4 x 128 of 512 per SIMD), so a streaming kernel enqueued beside it waits for its end, and the pieces' own
+  // launch tails cost 0.3 ms per C360 tick.
   const KernelKind kind = pick_kernel(b);
   int npieces = 1;
-  if (kind == KernelKind::Ring && b.tune.run1_pieces != 1) {
-    const uint64_t per_launch = (uint64_t)b.dev.num_cus * 16u * (uint64_t)std::max(1, b.tune.ring_rounds) * 64u;   // rows
-    const uint64_t most = (uint64_t)vol;
-    // measured (profiles/r05_sweeps.txt): more than one piece is slower - predict_fields_ring_kernel takes all of a CU's
-    // vector registers (4 x 128 of 512 per SIMD), so a streaming kernel enqueued beside it waits for its end, and the
-    // pieces' own launch tails cost 0.3 ms per C360 tick.  One piece unless asked for.
-    (void)most; (void)per_launch;
-    npieces = b.tune.run1_pieces > 1 ? b.tune.run1_pieces : 1;
-    npieces = std::max(1, std::min(npieces, r.jm / 8));
-  }
+  if (kind == KernelKind::Ring && b.tune.run1_pieces > 1) npieces = std::max(1, std::min(b.tune.run1_pieces, r.jm / 8));
   std::vector<int> j_lo((size_t)npieces + 1, 0);
   for (int q = 1; q <= npieces; ++q) j_lo[(size_t)q] = q == npieces ? r.jm : (int)((int64_t)r.jm * q / npieces / 4 * 4);
   while (b.run1_prep.size() < (size_t)npieces) {
@@ -2221,6 +2259,9 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   const bool tracing = trace_from >= 0;
   static std::atomic<unsigned> tick_no{0};
   TickTrace trace;
+  // however this call ends - judge_flags / raise_flag_errors throw after the read-back too - the thread's pointer to
+  // `trace` does not outlive it
+  struct TraceReset { ~TraceReset() { g_tick_trace = nullptr; } } trace_reset;
   const unsigned tick = tick_no.fetch_add(1);
   g_tick_trace = (tracing && tick >= (unsigned)trace_from && tick <= (unsigned)trace_from + 2u) ? &trace : nullptr;
   TICK_MARK("set-up");
@@ -2335,8 +2376,8 @@ int OHXBoosterKernelSymbolRows(BoosterHandle handle, DMatrixHandle dmat, const c
   tune.grid_im = d->grid_im;
   tune.grid_jm = d->grid_jm;
   tune.grid_row0 = d->grid_row0;
-  leaf_room(*b, d->nrow, a.tree_end - a.tree_begin, tune, tune.grid_im, tune.grid_jm, tune.grid_row0);
-  if (d->ncol == 27) (void)defer_prepare(*b, d->nrow, tune, nullptr);
+  leaf_room(*b, d->nrow, a.tree_end - a.tree_begin, tune, tune.grid_im, tune.grid_jm, tune.grid_row0, /*plan_only=*/true);
+  if (d->ncol == 27) (void)defer_plan(*b, d->nrow, tune);
   b->symbol = predict_kernel_symbols_rows(pick_kernel(*b), device_forest(*b), a, b->dev.num_cus, tune);
   *out = b->symbol.c_str();
   API_END();

@@ -179,8 +179,9 @@ struct LaunchTuning {
   // ring kernels: tiles per wave and launch (0 = one launch for the whole batch).  C360 step 24.28 ms at 16, 24.13 at 64,
   // 24.07 in one launch; the fused fields kernel 26.85 / 26.65 / 27.05 (profiles/r04_sweeps.txt)
   int ring_rounds = 64;
-  // OH Run1 on a big slab: ranges of j walked one after the other, the next one's feature engineering and the last
-  // one's post-processing beside the walk (capi.cpp run1_device): 0 = as many as pay, 1 = one piece, n = n pieces
+  // OH Run1 in ranges of j walked one after the other, the next one's feature engineering and the last one's
+  // post-processing beside the walk (capi.cpp run1_device): an experiment knob - 0 and 1 = one piece (the default; pieces
+  // measured slower), n > 1 = n pieces
   int run1_pieces = 0;
   // ring kernels: CUs left free (a ring block owns its CU - all of its vector registers and LDS - for the length of a
   // launch, so a collective's kernels enqueued beside it only get on the chip at a launch boundary; 0 = take them all)

@@ -957,3 +957,43 @@ def test_fused_fields_small_slab_with_its_trees_split_over_waves(torch_cuda, dee
         assert np.array_equal(helpers.bits(margins[0]), helpers.bits(margin_ref)), split
         assert np.all(oh[:, :, :k1 - 1] == 0)
         assert helpers.ulp_diff(oh[:, :, k1 - 1:], oh_ref[:, :, k1 - 1:]).max() <= 2, split
+
+
+def test_host_form_predict_on_borrowed_rows_waits_for_the_caller_s_default_stream(torch_cuda, small_model, tmp_path):
+    """(r6) A matrix made by OHXDMatrixCreateFromDevice borrows the caller's HBM; the host-form calls on it
+    (XGBoosterPredict, XGDMatrixSaveBinary) run on the library's own non-blocking stream and must not read the rows before
+    what the caller enqueued on the default stream - torch's - has filled them.  The rows start as NaN everywhere (every
+    split takes its default child); a long queue of work and then the copy of the real rows are enqueued on torch's stream
+    and the predict called at once, no synchronise: the margins are the real rows' margins, bit for bit against the
+    oracle - which they are not when the library does not wait (seen with order_behind_caller taken out)."""
+    torch = torch_cuda
+    grid = synth.GRIDS["C12"]
+    n = grid[0] * grid[1] * 24
+    real = torch.empty((n, synth.NFEAT), dtype=torch.float32, device="cuda:0")
+    synth.rows_device(grid, 0, n, real)
+    want = helpers.oracle_predict(small_model.image, real.cpu().numpy(), synth.XX_MISS)
+    rows = torch.full((n, synth.NFEAT), float("nan"), dtype=torch.float32, device="cuda:0")
+    busy = torch.randn((4096, 4096), device="cuda:0")
+    torch.cuda.synchronize()
+    b = capi.Booster(model_buffer=small_model.image)
+    d = capi.DMatrix(device_ptr=rows.data_ptr(), nrow=n, ncol=synth.NFEAT, missing=synth.XX_MISS)
+    d.set_grid(grid[0], grid[1], 0)
+    for _ in range(40):                               # tens of milliseconds in front of the copy, on torch's stream
+        busy = busy @ busy
+        busy = busy / busy.abs().max()
+    rows.copy_(real, non_blocking=True)
+    got = b.predict(d)                                # host form, straight away
+    assert np.array_equal(helpers.bits(got), helpers.bits(want))
+    # ... and the same for the matrix written to a file
+    rows.fill_(float("nan"))
+    for _ in range(40):
+        busy = busy @ busy
+        busy = busy / busy.abs().max()
+    rows.copy_(real, non_blocking=True)
+    d.save_binary(str(tmp_path / "rows.bin"))
+    torch.cuda.synchronize()
+    back = capi.DMatrix.from_file(str(tmp_path / "rows.bin"))
+    assert np.array_equal(helpers.bits(b.predict(back)), helpers.bits(want))
+    back.free()
+    d.free()
+    b.free()

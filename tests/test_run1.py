@@ -69,9 +69,10 @@ def test_run1_gpu_vs_oracle(deep_model, dynamic, grid):
 @pytest.mark.parametrize("grid,pieces,dynamic", [((37, 11, 72), 2, True), ((24, 30, 137), 3, False), ((40, 53, 72), 5, True),
                                                  ((144, 200, 72), 3, True), ((144, 200, 72), 4, False)])
 def test_run1_in_pieces_is_run1(deep_model, grid, pieces, dynamic):
-    """(r5) OH Run1 walks a big slab in ranges of j - the next range's feature engineering and the last one's mask and
-    unit conversion on a second stream beside the walk (capi.cpp run1_device; a C360 slab by itself, here forced by
-    ohx_run1_pieces on grids whose j extent is no multiple of the brick's four, small enough for the trees-split-over-
+    """(r5) OH Run1 can walk a slab in ranges of j - the next range's feature engineering and the last one's mask and
+    unit conversion on a second stream beside the walk (capi.cpp run1_device; never by itself - one piece is the default,
+    pieces measured slower - but on request: ohx_run1_pieces > 1, here on grids whose j extent is no multiple of the
+    brick's four, small enough for the trees-split-over-
     waves form and big enough for the ring kernel): every output, the DIAG dumps included, is what one piece gives, bit for
     bit - and that is checked against the oracle; with -999.0 and NaN among the inputs (the rows that hold them go
     through each piece's own second launch)."""
