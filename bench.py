@@ -138,6 +138,29 @@ def cpu_topology():
     return threads, (len(cores) or threads), (len(sockets) or 1)
 
 
+def cpu_quota():
+    """CPUs' worth of time the container's cgroup grants this process (cgroup v2 cpu.max, v1 cpu.cfs_quota_us), or None
+    when there is no limit to be seen.  A GPU box of this pool shows all of its host's 256 hardware threads in the
+    affinity mask and grants a share of them: past that many threads a team only queues for the quota."""
+    def read(path):
+        try:
+            return open(path).read().split()
+        except OSError:
+            return None
+    rel = ""
+    for line in (read("/proc/self/cgroup") or []):
+        if line.startswith("0::"):
+            rel = line[3:].strip()
+    for base in ("/sys/fs/cgroup" + rel, "/sys/fs/cgroup"):
+        w = read(os.path.join(base, "cpu.max"))
+        if w and len(w) == 2 and w[0] != "max":
+            return float(w[0]) / float(w[1])
+    q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+    if q and per and float(q[0]) > 0:
+        return float(q[0]) / float(per[0])
+    return None
+
+
 def kernel_source_hash():
     """Identifies the kernels a committed PMC measurement was taken on (profiles/*_traffic.json)."""
     import hashlib
@@ -210,13 +233,24 @@ def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
         synth.field_device(grid, feat, t)
         fields.append(t)
     full = budget_s >= 10
-    levels = min(km, 8) if full else 1
+    # the thread sweep: one thread (how a GEOS rank runs), 16, 64, 128, 256 as far as the host has them,
+    # every physical core and every hardware thread; the sample grows with the team so that a tick stays seconds long
+    quota = cpu_quota()
+    share = max(1, int(round(quota))) if quota else None
+    points = sorted({t for t in (1, 16, 64, 128, 256, phys_cores, cores, share or 1) if 1 <= t <= cores}) if full else sorted({1, cores})
     workdir = tempfile.mkdtemp(prefix="ohx_cpu_leg_")
+    sweep = []
     try:
-        oh1, t_one = fortran_cpu_leg(model_image, grid, fields, 1, 1, workdir, 2)
-        oh, t_all = fortran_cpu_leg(model_image, grid, fields, levels, cores, workdir, 3 if full else 2)
+        for t in points:
+            lv = 1 if (t == 1 or not full) else (2 if t < 64 else min(km, 8))
+            oh_t, ticks = fortran_cpu_leg(model_image, grid, fields, lv, t, workdir, 2)
+            sweep.append({"threads": t, "levels": lv, "gridcells": plane * lv, "value": plane * lv / min(ticks[1:]),
+                          "ticks_s": [round(x, 4) for x in ticks], "oh": oh_t})
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
+    best = max(sweep, key=lambda e: e["value"])
+    one = sweep[0]
+    oh, t_all, levels, t_one = best["oh"], best["ticks_s"], best["levels"], one["ticks_s"]
     n = plane * levels
     steady, steady_one = min(t_all[1:]), min(t_one[1:])
     # the checker's verdict: the same fields through the GPU's fused call (gather, PL/100, walk, 10**) vs the
@@ -232,17 +266,26 @@ def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
     if ulp > 2:
         raise SystemExit(f"bench: GPU OH differs from the Fortran CPU path by {ulp} ulp on the cpu_baseline sample")
     del fields, oh_gpu
-    base = {"value": n / steady, "unit": "gridcells/s", "cores": phys_cores, "threads": cores, "sockets": sockets,
+    used = best["threads"]
+    base = {"value": n / steady, "unit": "gridcells/s", "cores": min(used, phys_cores), "threads": used, "sockets": sockets,
+            "host_cores": phys_cores, "host_threads": cores, "cgroup_cpu_quota": quota,
             "kind": "port", "cpu_model": cpu_model_name(),
-            "sample": f"first {levels} of {km} levels ({n} gridcells) of the batch: oracle/lib/oh_mock_driver_oracle = the "
+            "sample": f"the BEST point of the thread sweep in `scaling`: OMP_NUM_THREADS={used} on the first {levels} of {km} "
+                      f"levels ({n} gridcells) of the batch: oracle/lib/oh_mock_driver_oracle = the "
                       f"Fortran host's predict_OH_with_XGB (SoA->AoS gather, XGDMatrixCreateFromMat, XGBoosterPredict, "
-                      f"10**pred; OH_GridCompMod.F90:308-374) linked against oracle/xgb_oracle.c, OMP_NUM_THREADS={cores} "
-                      f"(every hardware thread of the {phys_cores} cores on {sockets} socket(s)) "
+                      f"10**pred; OH_GridCompMod.F90:308-374) linked against oracle/xgb_oracle.c (host: {phys_cores} cores / "
+                      f"{cores} hardware threads on {sockets} socket(s)), threads "
                       f"pinned (OMP_PROC_BIND=spread OMP_PLACES=cores; gather and 10** single-threaded as in the "
                       f"reference); {len(t_all)} ticks in one process, value = the fastest tick after the first "
-                      f"({steady:.2f} s); libxgboost 1.6.0 itself is not available here.  All threads give about ten times "
-                      f"one thread, not {cores} times: the walk is bound by memory latency on the booster's 112 MB of raw "
-                      f"nodes, far beyond the caches - a baseline, not a measure of the GPU kernel (that is roofline.frac)",
+                      f"({steady:.2f} s); libxgboost 1.6.0 itself is not available here.  The oracle's raw nodes (112 MB, far "
+                      f"beyond the caches) live in one huge-page arena replicated per NUMA node, and a block's rows are "
+                      f"walked sixteen side by side, so the walk's cache misses overlap (round 6; xgboost 1.6.0 walks them "
+                      f"one after the other: the same leaves, the same float32 sums).  What is left of a many-thread tick is "
+                      f"largely the reference's own single-threaded gather and 10**; and a team larger than the CPU share "
+                      f"the box grants this job (cgroup_cpu_quota: {quota}; 16 on a one-GPU box of this pool, whatever the "
+                      f"affinity mask shows) only queues for it, which is why the sweep falls off beyond that many threads "
+                      f"- a baseline, not a measure of the GPU kernel (that is roofline.frac)",
+            "scaling": [{k: v for k, v in e.items() if k != "oh"} for e in sweep],
             "ticks_s": [round(t, 4) for t in t_all],
             "first_tick_s": round(t_all[0], 4),
             "load_s": round(max(t_all[0] - steady, 0.0), 4),

@@ -107,6 +107,15 @@ int XGBoosterPredict(BoosterHandle handle, DMatrixHandle dmat, int option_mask, 
  *   "ohx_run1_pieces" experiment knob of OHXBoosterRun1[Device]: n > 1 walks n ranges of j one after the other, with the
  *                     feature engineering of the next and the post-processing of the last on a second stream beside
  *                     the walk; 0 and 1 = one piece (default: measured, pieces are slower - profiles/r05_sweeps.txt)
+ *   "ohx_copy_engine" kernel (default) | dma | auto, process-wide (the handle may be NULL): how REGISTERED host arrays
+ *                     cross PCIe.  kernel = a list of arrays per launch of a copy kernel (the GPU reads / writes the
+ *                     caller's memory itself; the one list that crosses under the walk by DMA); dma = every array by
+ *                     hipMemcpyAsync (the DMA engines: a fixed price per array, no wave on any CU); auto = the host form
+ *                     of OHXBoosterRun1 times its own first ticks both ways (two of warm-up, then eight of each) and keeps
+ *                     the faster, trying again every 512 ticks.  Measured at 1, 2, 3 and 6 ranks on a card
+ *                     (profiles/r06_ranks_per_gpu_block_48x24_engines.json): the kernels win at every count (a rank's tick
+ *                     0.29 against 0.61 ms alone, 1.35 against 3.13 ms at six), auto says so every time, and its trial
+ *                     costs the tail - hence not the default.  The same bits either way.
  *   "ohx_register_host"  0 | 1, process-wide (the handle may be NULL): the host arrays handed to OHXBoosterRun1,
  *                     OHXOHPostProcess and OHXBoosterPredictFields are registered with the GPU driver the first time
  *                     they are seen and moved by DMA - a rank-sized block's forty arrays by ONE copy launch - from
@@ -337,6 +346,10 @@ int OHXBoosterKernelSymbolRows(BoosterHandle handle, DMatrixHandle dmat, const c
  * said on stderr by the next call that reads the flags back.  Waits for `stream`.  (The reference asserts rc == 0 on
  * XGBoosterPredict, OH_GridComp/OH_GridCompMod.F90:356-358: a time-out must not end a model run.) */
 int OHXBoosterRingReruns(BoosterHandle handle, void* stream, bst_ulong* out);
+/* What "ohx_copy_engine" = auto (when asked for) has decided for OHXBoosterRun1's host form on this booster: *choice = -1 while it is
+ * still trying (or when auto is not in charge: the engine was set, or the arrays are not registered), 0 = copy kernels,
+ * 1 = DMA; *trials = how many trials have ended, *picked_dma = how many of them picked DMA.  Any of the three may be NULL. */
+int OHXBoosterCopyEngineChoice(BoosterHandle handle, int* choice, unsigned* trials, unsigned* picked_dma);
 
 /* ------------------------------------------------------------------------
  * Part 4 — reassembling the OH field across the GPUs of a node (additive)

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "OHXDeviceCount", "OHXDMatrixCreateFromDevice", "OHXDMatrixSetGrid", "OHXDMatrixGetGrid", "OHXDMatrixInferGrid", "OHXBoosterPredictDevice", "OHXBoosterCheck",
     "OHXBoosterPredictFields", "OHXBoosterPredictFieldsDevice", "OHXBoosterRun1", "OHXBoosterRun1Device", "OHXOHPostProcess", "OHXOHPostProcessDevice",
     "OHXJulianDay", "OHXSolarGeometry", "OHXSolarGeometryDevice", "OHXBoosterGetInfo", "OHXBoosterKernelSymbol", "OHXBoosterKernelSymbolRows",
-    "OHXBoosterRingReruns", "OHXUnregisterHost", "OHXReleaseScratch",
+    "OHXBoosterRingReruns", "OHXBoosterCopyEngineChoice", "OHXUnregisterHost", "OHXReleaseScratch",
     "OHXCommGetUniqueId", "OHXCommInitRank", "OHXCommFree", "OHXCommInfo", "OHXShardRows", "OHXAllGatherOH",
 ]
 # the subset QuickChem's xgb_fortran_api binds (Shared/xgb_fortran_api.F90:19-119)
@@ -124,6 +124,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.OHXBoosterKernelSymbol.argtypes = [vp, u64, C.POINTER(C.c_char_p)]
     lib.OHXBoosterKernelSymbolRows.argtypes = [vp, vp, C.POINTER(C.c_char_p)]
     lib.OHXBoosterRingReruns.argtypes = [vp, vp, C.POINTER(u64)]
+    lib.OHXBoosterCopyEngineChoice.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     lib.OHXUnregisterHost.argtypes = [vp]
     lib.OHXReleaseScratch.argtypes = []
     lib.OHXCommGetUniqueId.argtypes = [vp]
@@ -383,6 +384,13 @@ class Booster:
         out = C.c_uint64()
         check(self.lib, self.lib.OHXBoosterRingReruns(self.handle, stream, C.byref(out)))
         return int(out.value)
+
+    def copy_engine_choice(self):
+        """-> (choice, trials, picked_dma): what ohx_copy_engine = auto decided for this booster's Run1 host form
+        (-1 trying / not in charge, 0 copy kernels, 1 DMA), and how its trials went (include/ohxgb.h)."""
+        c, t, d = C.c_int(), C.c_uint(), C.c_uint()
+        check(self.lib, self.lib.OHXBoosterCopyEngineChoice(self.handle, C.byref(c), C.byref(t), C.byref(d)))
+        return int(c.value), int(t.value), int(d.value)
 
     def kernel_symbol(self, ncol: int) -> str:
         out = C.c_char_p()

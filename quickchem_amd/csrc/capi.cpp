@@ -366,6 +366,17 @@ HostRegistry g_host_registry;
 // arguments over the same link); a 48 x 24 x 72 tick 0.349 / 0.345 / 0.328 / 0.339 / 0.389 ms at 256 / 128 / 64 / 32 / 16
 // blocks, 0.398 with a block per KiB (profiles/r05_sweeps.txt)
 std::atomic<uint32_t> g_copy_blocks{64};
+// "ohx_copy_engine" (process-wide): how REGISTERED host arrays cross.  kernel (default) = lists by copy_arrays_kernel (one
+// launch per list; the one list that crosses under the walk by DMA, OHX_COPY_POST_BLOCKS); dma = every array by
+// hipMemcpyAsync (the DMA engines: a fixed price per array, no wave on any CU); auto = OHXBoosterRun1's host form times
+// its own ticks both ways and keeps the faster (CopyEngineTrial below), everything else as kernel.
+// Round 5 supposed that DMA would win once ranks share the card (a copy kernel's waves, waiting on PCIe on every CU, hold
+// up the other ranks' walks).  Measured (profiles/r06_ranks_per_gpu_block_48x24_engines.json, a 48 x 24 x 72 tick at 1 / 2 / 3 / 6
+// ranks): copy kernels 0.290 / 0.583 / 0.678 / 1.348 ms, all by DMA 0.614 / 1.258 / 1.738 / 3.131 ms - forty fixed prices
+// a tick lose at every count, auto picked "kernel" on every rank of every run, and its trial's eight DMA ticks are what
+// its p99 is made of (3.8 against 1.9 ms at six ranks).  So kernel is the default and auto is there to be asked for.
+enum CopyEngine : int { kCopyKernel = 0, kCopyDma = 1, kCopyAuto = 2 };
+std::atomic<int> g_copy_engine{kCopyKernel};
 struct HostMover {
   static constexpr size_t kKernelBytesMax = 64u << 20;
   CopyList list;
@@ -373,8 +384,9 @@ struct HostMover {
   hipStream_t stream;
   bool to_device;
   uint32_t blocks_override = 0;       // blocks of this mover's launches, when its owner knows better than the defaults
-  bool by_dma = false;                // registered arrays too go through hipMemcpyAsync (the DMA engines: no wave on a CU)
-  explicit HostMover(hipStream_t s, bool h2d) : stream(s), to_device(h2d) {}
+  bool by_dma;                        // registered arrays too go through hipMemcpyAsync (the DMA engines: no wave on a CU)
+  explicit HostMover(hipStream_t s, bool h2d)
+      : stream(s), to_device(h2d), by_dma(g_copy_engine.load(std::memory_order_relaxed) == kCopyDma) {}
   void add(float* dst, const float* src, size_t count) {
     if (count == 0) return;
     const void* host = to_device ? (const void*)src : (const void*)dst;
@@ -395,7 +407,7 @@ struct HostMover {
   void add_slice(float* dev, const float* host_base, size_t whole, size_t offset, size_t count) {
     if (count == 0) return;
     void* mapped = nullptr;
-    if (g_host_registry.want(host_base, whole * sizeof(float), &mapped) && mapped != nullptr && list.count < kCopyListMax &&
+    if (g_host_registry.want(host_base, whole * sizeof(float), &mapped) && mapped != nullptr && !by_dma && list.count < kCopyListMax &&
         list_bytes + count * sizeof(float) <= kKernelBytesMax) {
       float* m = static_cast<float*>(mapped) + offset;
       list.src[list.count] = to_device ? m : dev;
@@ -427,6 +439,7 @@ struct HostMover {
     static const int back_blocks = [] { const char* e = getenv("OHX_COPY_BACK_BLOCKS"); return e ? atoi(e) : 512; }();
     uint32_t blocks = (!to_device && back_blocks > 0) ? (uint32_t)back_blocks : g_copy_blocks.load(std::memory_order_relaxed);
     if (blocks_override > 0) blocks = blocks_override;
+    if (list.count == 0) return;
     HIP_CHECK(launch_copy_arrays(list, stream, blocks));
     list.count = 0;
     list_bytes = 0;
@@ -547,6 +560,42 @@ struct BoosterObj {
   hipStream_t s_copy = nullptr, s_exec = nullptr;
   hipEvent_t run1_fork = nullptr, run1_slab = nullptr, run1_join = nullptr, run1_clear = nullptr;
   std::vector<hipEvent_t> run1_prep, run1_walk, run1_feed_events;
+  // ohx_copy_engine = auto: the host form of Run1 on this booster decides by its own clock.  After two ticks of warm-up,
+  // eight ticks of each engine in runs of four (K K K K D D D D K K K K D D D D); the lower median wins; every 512 ticks
+  // the trial is run again (ranks come and go); a block of another size starts over.  Both engines give the same bits.
+  struct CopyEngineTrial {
+    size_t vol = 0;
+    unsigned tick = 0;                 // since the trial (re)started
+    int choice = -1;                   // -1 = trying
+    unsigned trials = 0, picked_dma = 0;
+    std::vector<double> seconds[2];
+    static constexpr unsigned kWarm = 2, kRun = 4, kEach = 8, kAgain = 512;
+    bool dma_now(size_t v) {
+      if (v != vol) { vol = v; tick = 0; choice = -1; seconds[0].clear(); seconds[1].clear(); }
+      if (choice >= 0 && tick >= kAgain) { tick = kWarm; choice = -1; seconds[0].clear(); seconds[1].clear(); }
+      if (choice >= 0) return choice == 1;
+      if (tick < kWarm) return false;
+      return ((tick - kWarm) / kRun) % 2 == 1;
+    }
+    void report(bool dma, double s) {
+      const unsigned t = tick++;
+      if (choice >= 0 || t < kWarm) return;
+      seconds[dma ? 1 : 0].push_back(s);
+      if (seconds[0].size() >= kEach && seconds[1].size() >= kEach) {
+        double med[2];
+        for (int e = 0; e < 2; ++e) {
+          std::sort(seconds[e].begin(), seconds[e].end());
+          med[e] = seconds[e][seconds[e].size() / 2];
+        }
+        choice = med[1] < med[0] ? 1 : 0;
+        ++trials;
+        picked_dma += (unsigned)choice;
+        if (getenv("OHX_DEBUG"))
+          fprintf(stderr, "[libohxgb] copy engine trial %u on a block of %zu gridcells: median tick %.1f us by copy kernels, %.1f us by DMA -> %s\n",
+                  trials, vol, med[0] * 1e6, med[1] * 1e6, choice ? "dma" : "kernel");
+      }
+    }
+  } copy_trial;
   PinnedBuf<int32_t> h_slab;
   std::vector<DevBuf<float>> d_stage;  // fused host path: per-field staging
   DevBuf<float> d_stage_out, d_stage_margin;
@@ -1329,6 +1378,11 @@ int XGBoosterSetParam(BoosterHandle handle, const char* name, const char* value)
   API_BEGIN();
   if (name == nullptr || value == nullptr) throw OhxError("XGBoosterSetParam: NULL argument");
   const std::string n(name), v(value);
+  if (n == "ohx_copy_engine") {                               // process-wide; the handle may be NULL
+    if (v != "kernel" && v != "dma" && v != "auto") throw OhxError("ohx_copy_engine must be kernel, dma or auto");
+    g_copy_engine.store(v == "kernel" ? kCopyKernel : (v == "dma" ? kCopyDma : kCopyAuto));
+    return 0;
+  }
   if (n == "ohx_register_host" && handle == nullptr) {       // process-wide: settable before any booster exists
     g_host_registry.on.store(atoi(value) != 0);
     if (atoi(value) == 0) g_host_registry.release_all();
@@ -2139,12 +2193,13 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
     size_t plane, km;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t post_blocks = 0;
-    bool post_by_dma = false;
+    bool post_by_dma = false, all_by_dma = false;
     void stage(int which, int k1, int k2) {
       HostMover in(b->s_copy, true);
+      in.by_dma = all_by_dma;
       if (which == 2) {
         in.blocks_override = post_blocks;
-        in.by_dma = post_by_dma;
+        in.by_dma = post_by_dma || all_by_dma;
       }
       for (size_t i = 0; i < nin; ++i) {
         if (ins[i].stage != which || same_as[i] >= 0) continue;
@@ -2253,6 +2308,11 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
   static const int knob_post_blocks = [] { const char* e = getenv("OHX_COPY_POST_BLOCKS"); return e ? atoi(e) : -1; }();
   feed.post_blocks = knob_post_blocks > 0 ? (uint32_t)knob_post_blocks : 0u;
   feed.post_by_dma = knob_post_blocks < 0;
+  // ohx_copy_engine: dma, or auto's verdict (or its trial's turn) for a tick on registered arrays
+  const int engine = g_copy_engine.load(std::memory_order_relaxed);
+  const bool trying = engine == kCopyAuto && g_host_registry.on.load(std::memory_order_relaxed);
+  feed.all_by_dma = engine == kCopyDma || (trying && b->copy_trial.dma_now(vol));
+  const auto tick_began = std::chrono::steady_clock::now();
   hipStream_t main = nstreams == 1 ? b->s_copy : b->s_exec;
   // OHX_RUN1_TRACE=<n> (1 = 50): the host's time marks of ticks n .. n + 2 of this process on stderr
   static const int trace_from = [] { const char* e = getenv("OHX_RUN1_TRACE"); const int n = e ? atoi(e) : -1; return n == 1 ? 50 : n; }();
@@ -2275,6 +2335,7 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
     throw;
   }
   HostMover back(main, false);
+  back.by_dma = feed.all_by_dma;
   back.add(h.oh, d.oh, vol);
   if (h.ndwet) back.add(h.ndwet, d.ndwet, vol);
   if (h.oh_boost) back.add(h.oh_boost, d.oh_boost, vol);
@@ -2298,6 +2359,7 @@ int OHXBoosterRun1(BoosterHandle handle, const OHXRun1Args* args) {
     raise_flag_errors(*b, main);        // waits for the stream
   }
   TICK_MARK("done");
+  if (trying) b->copy_trial.report(feed.all_by_dma, std::chrono::duration<double>(std::chrono::steady_clock::now() - tick_began).count());
   if (g_tick_trace) g_tick_trace->print(tick);
   g_tick_trace = nullptr;
   API_END();
@@ -2394,6 +2456,16 @@ int OHXBoosterRingReruns(BoosterHandle handle, void* stream, bst_ulong* out) {
     HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     *out = n;
   }
+  API_END();
+}
+
+int OHXBoosterCopyEngineChoice(BoosterHandle handle, int* choice, unsigned* trials, unsigned* picked_dma) {
+  API_BEGIN();
+  BoosterObj* b = as_booster(handle);
+  const bool in_charge = g_copy_engine.load(std::memory_order_relaxed) == kCopyAuto && g_host_registry.on.load(std::memory_order_relaxed);
+  if (choice) *choice = in_charge ? b->copy_trial.choice : -1;
+  if (trials) *trials = b->copy_trial.trials;
+  if (picked_dma) *picked_dma = b->copy_trial.picked_dma;
   API_END();
 }
 

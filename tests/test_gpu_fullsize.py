@@ -95,8 +95,9 @@ def _hinted_vs_unhinted(torch, model, grid, row0, n, how):
 @pytest.mark.parametrize("how", ["hint", "infer", "lazy"])
 def test_whole_c360_batch_with_the_default_tiling(full_model, how):
     """The headline workload exactly as bench.py times it: all 55 987 200 rows of C360 L72 in ONE DMatrix,
-    4x4x4 bricks from OHXDMatrixSetGrid(360, 2160, 0) - 32-bit brick numbering, 874 800 tiles, a train of 86
-    launches; with the level size inferred (8 cells x 8 levels per wave); and with nothing said at all
+    4x4x4 bricks from OHXDMatrixSetGrid(360, 2160, 0) - 32-bit brick numbering, 874 800 tiles, four launches of
+    the ring kernel (64 rounds of 256 x 16 tiles each; the tile kernel's train was 86 launches until round 3);
+    with the level size inferred (8 cells x 8 levels per wave); and with nothing said at all
     ("lazy": OHXBoosterPredictDevice looks for the level size itself at the first predict)."""
     import torch
     torch.cuda.set_device(0)

@@ -455,11 +455,21 @@ b = capi.Booster(model_buffer=model.image)
 st = helpers.run1_state((37, 11, 40), seed=3)
 call = b.run1_prepare(st, dynamic_k_range=True, want_boost=True, want_ndwet=True, want_diag=True)
 plain = {k: v.copy() for k, v in b.run1_call(call).items() if isinstance(v, np.ndarray)}
+import os
+engine = os.environ.get("OHX_TEST_COPY_ENGINE")
+if engine:
+    b.set_param("ohx_copy_engine", engine)
 b.set_param("ohx_register_host", "1")
-for tick in range(4):
+# (auto: two ticks of warm-up, then K K K K D D D D K K K K D D D D and a verdict - 24 ticks see every phase of it)
+for tick in range(24 if engine == "auto" else 4):
     got = b.run1_call(call)
     for k, v in plain.items():
         assert np.array_equal(got[k].view(np.uint32), v.view(np.uint32)), (tick, k)
+choice, trials, picked = b.copy_engine_choice()
+if engine == "auto":
+    assert choice in (0, 1) and trials == 1 and picked == choice, (choice, trials, picked)
+else:
+    assert choice == -1 or engine is None, (engine, choice)
 b.set_param("ohx_register_host", "0")
 print("KNOBS_OK")
 """
@@ -474,7 +484,10 @@ def test_the_host_tick_under_each_of_its_experiment_knobs():
     import sys
     for env in ({"OHX_RUN1_GATE": "1"}, {"OHX_RUN1_SLAB_IN_PLACE": "1"}, {"OHX_RUN1_GATE": "1", "OHX_RUN1_SLAB_IN_PLACE": "1"},
                 {"OHX_RUN1_STREAMS": "1"}, {"OHX_COPY_POST_BLOCKS": "0"}, {"OHX_COPY_POST_BLOCKS": "8", "OHX_COPY_BACK_BLOCKS": "0"},
-                {"OHX_RUN1_STREAMS": "1", "OHX_RUN1_SLAB_IN_PLACE": "1", "OHX_COPY_BACK_BLOCKS": "32"}):
+                {"OHX_RUN1_STREAMS": "1", "OHX_RUN1_SLAB_IN_PLACE": "1", "OHX_COPY_BACK_BLOCKS": "32"},
+                # (r6) ohx_copy_engine: every list and the copy-back by the DMA engines, by copy kernels, and auto's trial
+                {"OHX_TEST_COPY_ENGINE": "dma"}, {"OHX_TEST_COPY_ENGINE": "kernel"}, {"OHX_TEST_COPY_ENGINE": "auto"},
+                {"OHX_TEST_COPY_ENGINE": "dma", "OHX_RUN1_STREAMS": "1"}):
         r = subprocess.run([sys.executable, "-c", KNOB_CHILD, helpers.ROOT], env=dict(os.environ, **env), capture_output=True,
                            text=True, timeout=600, cwd=helpers.ROOT)
         assert r.returncode == 0 and "KNOBS_OK" in r.stdout, (env, r.stdout[-1500:], r.stderr[-3000:])

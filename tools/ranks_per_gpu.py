@@ -12,7 +12,11 @@ Starts P fresh processes on ONE GPU, P in --ranks.  Each is a "rank" that owns C
    run1:       OHXBoosterRun1, the HOST form - the one call quickchem_amd/fortran/oh_gridcomp.F90 makes on a Boost tick
                (oh_run1_boost: 37 import arrays in, INTERNAL OH, OH_boost and NDWET out; OH_GridCompMod.F90:1444-1595)
    run1_registered:  the same with XGBoosterSetParam("ohx_register_host", "1"): the arrays are registered with the
-               driver at their first tick and read / written by DMA from then on
+               driver at their first tick and read / written by the GPU in place from then on - by copy kernels
+               (run1_registered: ohx_copy_engine = kernel, the default), by the DMA engines (run1_registered_dma), or
+               whichever of the two the library's own trial finds faster on this card at this moment
+               (run1_registered_auto); run1_registered_oh_only is the default engine with INTERNAL OH as the only output
+               (no OH_boost, no NDWET: what the shell asks for when HISTORY wants neither)
 from pageable numpy arrays.  The ranks start their ticks together (a start time handed to all of them).  Prints ONE JSON
 object: per P the aggregate gridcells/s over the common window, per-tick latency p50 / p95 / max, the first tick, and
 the HBM the processes hold together.
@@ -32,6 +36,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+RUN1_MODES = ("run1", "run1_registered", "run1_registered_dma", "run1_registered_auto", "run1_registered_oh_only")
 
 
 def hbm_free_bytes():
@@ -113,11 +120,21 @@ def child(args):
     call = b.run1_prepare(st, dynamic_k_range=True, want_boost=True, want_ndwet=True)
     windows = {"reference": [t_ref0, t_ref1], "fused": [t_ref1, t_fused1]}
     first_oh = None
-    for mode in ("run1", "run1_registered"):
+    # (r6) registered arrays three ways: ohx_copy_engine = kernel (the default), dma, and auto, whose first eighteen ticks
+    # are its trial of the other two and are among the timed ones, as a rank sees them; then the default once more with
+    # only INTERNAL OH coming back
+    for mode in RUN1_MODES:
         ticks[mode], ends[mode] = [], []
-        b.set_param("ohx_register_host", "1" if mode == "run1_registered" else "0")
-        if mode == "run1_registered":
-            b.run1_call(call)                  # the tick that registers the arrays is not one of the timed ones
+        b.set_param("ohx_register_host", "0" if mode == "run1" else "1")
+        if mode != "run1":
+            b.set_param("ohx_copy_engine", {"run1_registered_dma": "dma", "run1_registered_auto": "auto"}.get(mode, "kernel"))
+            if mode == "run1_registered":
+                b.run1_call(call)              # the tick that registers the arrays is not one of the timed ones
+            if mode == "run1_registered_oh_only":
+                # what the shell asks for when HISTORY wants neither OH_boost nor DIAG_NDWET and Boost runs at every
+                # alarm (oh_gridcomp.F90: want_boost / want_ndwet): INTERNAL OH alone comes back
+                call = b.run1_prepare(st, dynamic_k_range=True, want_boost=False, want_ndwet=False)
+                b.run1_call(call)
         meet(mode)
         w0 = time.time()
         for tick in range(args.ticks):
@@ -126,6 +143,8 @@ def child(args):
             ticks[mode].append(time.perf_counter() - t0)
             ends[mode].append(time.time())
         windows[mode] = [w0, time.time()]
+        if mode == "run1_registered_auto":
+            out["copy_engine_choice"] = dict(zip(("choice", "trials", "picked_dma"), b.copy_engine_choice()))
         if first_oh is None:
             first_oh = r1["oh"].copy()
         else:
@@ -190,7 +209,8 @@ def parent(args):
             entry["hbm_held_all_ranks_bytes"] = max(r["hbm_free_before"] for r in ranks) - min(r["hbm_free_after"] for r in ranks)
         entry["run1_bytes_in_per_rank"] = ranks[0]["run1_bytes_in"]
         entry["run1_rows_predicted_per_rank"] = ranks[0]["run1_rows_predicted"]
-        for mode in ("reference", "fused", "run1", "run1_registered"):
+        entry["copy_engine_auto_chose"] = [{-1: "undecided", 0: "kernel", 1: "dma"}[r["copy_engine_choice"]["choice"]] for r in ranks]
+        for mode in ("reference", "fused") + RUN1_MODES:
             first = [r["ticks_s"][mode][0] for r in ranks]
             later = [t for r in ranks for t in r["ticks_s"][mode][1:]]
             # the interval in which EVERY rank is ticking steadily: from the last rank's first tick's end to the
