@@ -99,6 +99,9 @@ constexpr uint32_t kSuperMaxGroups = 1u << 14;
 // the tree's first 48 (groups 0-11): the kernels fetch them with one coalesced load per tree and wave (one record
 // per lane) and hand them from lane to lane.  emit_super pads the array by this much behind the last tree.
 constexpr uint32_t kSuperTopSlots = 48;
+// ... and the records of the first FOUR steps among its first 176 (4 fillers + 4 + 8 + 32 + 128): what the ring kernels
+// keep in LDS per tree (kernels.hip)
+constexpr uint32_t kSuperRingSlots = 176;
 
 // Per tree: where the walk starts.  Phase-0 trees start at super-node base + 4.  Phase-1 trees
 // (super-nodes start at odd levels) evaluate the root from this record - it is the same for
