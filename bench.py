@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="cpu_baseline leg: 0 = skip, < 10 = a one-level sample, else the fixed sample (8 levels, 3 ticks)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_inclusive measurement (host-pointer entry points)")
+    ap.add_argument("--no-full-oracle", action="store_true",
+                    help="skip the comparison of EVERY timed margin with the CPU oracle (the first 2^20 rows and 2^20 drawn rows stay)")
     ap.add_argument("--no-rank-ticks", action="store_true",
                     help="skip the GEOS-rank tick measurement (the shell's Boost tick and skip tick as child processes)")
     ap.add_argument("--shuffle", action="store_true", help="permute the rows (destroys spatial coherence)")
@@ -954,6 +956,24 @@ def main():
         if not np.array_equal(out_local[pick].cpu().numpy().view(np.uint32), want.view(np.uint32)):
             raise SystemExit("bench: GPU margins differ from the oracle on rows drawn from the whole batch")
         cpu["margins_bit_identical_on_random_rows"] = n_chk
+        # (r6) ... and, now that the oracle walks sixteen rows side by side, EVERY row of the timed output: the whole
+        # batch in pieces of 2^22 rows through the oracle's XGBoosterPredict, on as many threads as the box grants
+        if not args.no_full_oracle and args.cpu_seconds >= 10:
+            quota = cpu_quota()
+            lib.oracle_set_num_threads.argtypes = [C.c_int]
+            lib.oracle_set_num_threads(max(1, int(round(quota))) if quota else min(32, os.cpu_count() or 8))
+            t_full = time.perf_counter()
+            piece = 1 << 22
+            for lo in range(0, n_local, piece):
+                hi = min(n_local, lo + piece)
+                od = capi.DMatrix(rows[lo:hi].cpu().numpy(), missing=synth.XX_MISS, lib=lib)
+                want = ob.predict(od, copy=False)
+                same = np.array_equal(out_local[lo:hi].cpu().numpy().view(np.uint32), want.view(np.uint32))
+                od.free()
+                if not same:
+                    raise SystemExit(f"bench: GPU margins differ from the oracle in rows {lo} .. {hi - 1} of the batch")
+            cpu["margins_bit_identical_on_the_whole_batch"] = n_local
+            cpu["whole_batch_oracle_s"] = round(time.perf_counter() - t_full, 2)
 
     pcie = host_tick = None
     if rank == 0 and world == 1 and plain and not args.no_pcie and args.cpu_seconds > 0 and use_grid:
@@ -980,9 +1000,11 @@ def main():
                           "mean_path": round(model.mean_path, 3), "seed": synth.MODEL_SEED,
                           "build_s": round(t_model, 2)},
                 "kernel": args.kernel, "params": args.param, "missing_ppm": args.missing_ppm, "shuffled": bool(args.shuffle), "grid_hint": bool(use_grid), "grid_known_to_library": list(dmats[0].grid()), "verified": verified,
-                "verified_against": ("the whole timed output, bit for bit, against the `wide` kernel (other node format, no LDS tile, no grid hint); "
-                                     "the CPU oracle sees the first 2^20 rows and 2^20 rows drawn from the whole batch "
-                                     "(cpu_baseline.margins_bit_identical_on_first_rows / _on_random_rows)") if verified else None,
+                "verified_against": ("the whole timed output, bit for bit, against the `wide` kernel (other node format, no LDS tile, no grid hint)"
+                                     + ("; and against the CPU oracle, every row (cpu_baseline.margins_bit_identical_on_the_whole_batch)"
+                                        if cpu and cpu.get("margins_bit_identical_on_the_whole_batch") == n_local else
+                                        "; the CPU oracle sees the first 2^20 rows and 2^20 rows drawn from the whole batch "
+                                        "(cpu_baseline.margins_bit_identical_on_first_rows / _on_random_rows)")) if verified else None,
                 "parallelism": f"rows{world}", "gather_pieces": len(pieces) if gather else 0,
                 "gather_via": (args.gather if (world > 1 or force_dist) else None),
                 "planner_prices": prices if (world > 1 or force_dist) else None,
