@@ -83,9 +83,11 @@ def child(args):
         """Every mode starts on all ranks together (files beside the model file): ranks that ran their modes back to back
         drifted apart, and by the fourth mode the first rank had finished before the last had begun - a common window of
         negative length."""
+        # (the file names carry the rank count: the runs of a --ranks list share the directory, and the files of the run
+        # before let the ranks of this one through before their slowest peer had arrived - P = 3 windows of negative length)
         d = os.path.dirname(args.model)
-        open(os.path.join(d, f"at_{name}_{args.rank}"), "w").close()
-        while sum(os.path.exists(os.path.join(d, f"at_{name}_{r}")) for r in range(args.nranks)) < args.nranks:
+        open(os.path.join(d, f"at_{args.nranks}_{name}_{args.rank}"), "w").close()
+        while sum(os.path.exists(os.path.join(d, f"at_{args.nranks}_{name}_{r}")) for r in range(args.nranks)) < args.nranks:
             time.sleep(0.0005)
 
     t_ref0 = time.time()
