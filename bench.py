@@ -140,24 +140,25 @@ def cpu_topology():
     return threads, (len(cores) or threads), (len(sockets) or 1)
 
 
-def cpu_quota():
+def cpu_quota(root="/"):
     """CPUs' worth of time the container's cgroup grants this process (cgroup v2 cpu.max, v1 cpu.cfs_quota_us), or None
     when there is no limit to be seen.  A GPU box of this pool shows all of its host's 256 hardware threads in the
-    affinity mask and grants a share of them: past that many threads a team only queues for the quota."""
-    def read(path):
+    affinity mask and grants a share of them: past that many threads a team only queues for the quota.
+    `root`: where /proc and /sys hang (the tests hand it a directory of their own)."""
+    def read(*parts):
         try:
-            return open(path).read().split()
+            return open(os.path.join(root, *parts)).read().split()
         except OSError:
             return None
     rel = ""
-    for line in (read("/proc/self/cgroup") or []):
+    for line in (read("proc", "self", "cgroup") or []):
         if line.startswith("0::"):
-            rel = line[3:].strip()
-    for base in ("/sys/fs/cgroup" + rel, "/sys/fs/cgroup"):
-        w = read(os.path.join(base, "cpu.max"))
+            rel = line[3:].strip().lstrip("/")
+    for base in (os.path.join("sys", "fs", "cgroup", rel), os.path.join("sys", "fs", "cgroup")):
+        w = read(base, "cpu.max")
         if w and len(w) == 2 and w[0] != "max":
             return float(w[0]) / float(w[1])
-    q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+    q, per = read("sys", "fs", "cgroup", "cpu", "cpu.cfs_quota_us"), read("sys", "fs", "cgroup", "cpu", "cpu.cfs_period_us")
     if q and per and float(q[0]) > 0:
         return float(q[0]) / float(per[0])
     return None
@@ -1034,6 +1035,16 @@ def main():
             "run1_host": host_tick,
             "rank_ticks": shell_ticks,
         }
+        # the reference's own child is a BASELINE (oracle/_ref, the reference compiled in place): its figures go where
+        # the baselines are, the product's stay in rank_ticks
+        if shell_ticks and "ranks" in shell_ticks and cpu is not None:
+            ref = {P: arms.pop("reference_child") for P, arms in shell_ticks["ranks"].items() if "reference_child" in arms}
+            if ref:
+                cpu["rank_ticks_reference_child"] = {
+                    "what": "the same ticks (rank_ticks.what) through the reference's own OH_GridCompMod.F90, compiled in place "
+                            "into oracle/_ref/refchild: its feature engineering, gather, 10**x, mask and conversion on the "
+                            "rank's core, its five xgboost calls served by libohxgb.so on the GPU",
+                    "ranks": ref}
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

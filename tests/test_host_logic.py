@@ -205,3 +205,36 @@ def test_python_side_knows_the_librarys_ring_rounds_default():
     assert int(re.search(r"constexpr int kRingRoundsPermuted = (\d+);", hpp).group(1)) == capi.RING_ROUNDS_PERMUTED
     header = open(os.path.join(root, "include", "ohxgb.h")).read()
     assert f'"ohx_ring_rounds" ring kernels: tiles per wavefront and launch (default {capi.RING_ROUNDS_DEFAULT};' in header
+
+
+def test_bench_reads_the_cpu_share_a_cgroup_grants(tmp_path):
+    """(r6) bench.py's cpu_baseline sweeps threads and says why it peaks where it does: the box's cgroup quota.  cgroup v2
+    (cpu.max at the process's own group, or at the root), v1 (cfs quota / period), "max" and nothing at all."""
+    import bench
+
+    def tree(files):
+        root = tmp_path / f"r{len(list(tmp_path.iterdir()))}"
+        for rel, text in files.items():
+            p = root / rel
+            p.parent.mkdir(parents=True, exist_ok=True)
+            p.write_text(text)
+        root.mkdir(exist_ok=True)
+        return str(root)
+    assert bench.cpu_quota(tree({"proc/self/cgroup": "0::/process_api/abc\n", "sys/fs/cgroup/process_api/abc/cpu.max": "1600000 100000\n"})) == 16.0
+    assert bench.cpu_quota(tree({"proc/self/cgroup": "0::/\n", "sys/fs/cgroup/cpu.max": "250000 100000\n"})) == 2.5
+    assert bench.cpu_quota(tree({"proc/self/cgroup": "0::/\n", "sys/fs/cgroup/cpu.max": "max 100000\n"})) is None
+    assert bench.cpu_quota(tree({"sys/fs/cgroup/cpu/cpu.cfs_quota_us": "800000\n", "sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"})) == 8.0
+    assert bench.cpu_quota(tree({"sys/fs/cgroup/cpu/cpu.cfs_quota_us": "-1\n", "sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"})) is None
+    assert bench.cpu_quota(tree({})) is None
+
+
+def test_rank_tick_tool_sorts_ticks_into_boost_and_skip():
+    """(r6) tools/rank_tick_end_to_end.py: the driver's TICK_US lines -> (tick, us, nhms); quantiles of a list."""
+    import sys
+    sys.path.insert(0, os.path.join(helpers.ROOT, "tools"))
+    import rank_tick_end_to_end as rt
+    log = "noise\nTICK_US 0 600000.5 0\nTICK_US 1 73.2 10000\n OH is *NOT*\nTICK_US 24 471.0 0\n"
+    assert rt.parse_ticks(log) == [(0, 600000.5, 0), (1, 73.2, 10000), (24, 471.0, 0)]
+    q = rt.quantiles([5.0, 1.0, 3.0, 2.0, 4.0])
+    assert (q["n"], q["median"], q["max"], q["p10"]) == (5, 3.0, 5.0, 1.0) and abs(q["mean"] - 3.0) < 1e-12
+    assert rt.quantiles([]) is None
