@@ -138,6 +138,7 @@ LibStreams& lib_streams(int ordinal) {
     if (cur != ordinal) HIP_CHECK(hipSetDevice(ordinal));
     HIP_CHECK(hipStreamCreateWithFlags(&ls.exec, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&ls.copy, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ls.caller, hipEventDisableTiming));      // made here, under the lock: two threads may ask
     if (cur != ordinal) HIP_CHECK(hipSetDevice(cur));
   }
   return ls;
@@ -149,8 +150,12 @@ LibStreams& lib_streams(int ordinal) {
 // the library runs on the default stream.  A producer on a NON-blocking stream of the caller's is the caller's to
 // synchronise (include/ohxgb.h), or to name: the *Device forms take the stream.
 void order_behind_caller(int ordinal, hipStream_t s) {
+  // (one event per device, re-recorded by every such call: a wait takes the event's state as it is when the wait is
+  // enqueued, so a later record does not disturb an earlier call's wait; two threads at once serialise here - the pair
+  // record + wait must not interleave with another thread's)
+  static std::mutex mu;
   LibStreams& ls = lib_streams(ordinal);
-  if (ls.caller == nullptr) HIP_CHECK(hipEventCreateWithFlags(&ls.caller, hipEventDisableTiming));
+  std::lock_guard<std::mutex> g(mu);
   HIP_CHECK(hipEventRecord(ls.caller, nullptr));
   HIP_CHECK(hipStreamWaitEvent(s, ls.caller, 0));
 }
