@@ -270,7 +270,9 @@ def cpu_baseline(model_image, grid, booster, out_dev, budget_s):
         raise SystemExit(f"bench: GPU OH differs from the Fortran CPU path by {ulp} ulp on the cpu_baseline sample")
     del fields, oh_gpu
     used = best["threads"]
-    base = {"value": n / steady, "unit": "gridcells/s", "cores": min(used, phys_cores), "threads": used, "sockets": sockets,
+    # cores = what the team really ran on: its threads, capped by the host's cores and by the CPUs the cgroup grants
+    base = {"value": n / steady, "unit": "gridcells/s", "cores": int(min(used, phys_cores, quota or used)), "threads": used,
+            "sockets": sockets,
             "host_cores": phys_cores, "host_threads": cores, "cgroup_cpu_quota": quota,
             "kind": "port", "cpu_model": cpu_model_name(),
             "sample": f"the BEST point of the thread sweep in `scaling`: OMP_NUM_THREADS={used} on the first {levels} of {km} "
