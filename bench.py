@@ -1037,6 +1037,16 @@ def main():
             "run1_host": host_tick,
             "rank_ticks": shell_ticks,
         }
+        # the shell's own ticks on the rank-sized block, beside the library call's (run1_host.blocks[0] is that block)
+        if shell_ticks and "ranks" in shell_ticks and host_tick and host_tick["blocks"][0]["block"] == shell_ticks.get("block"):
+            for P, arms in shell_ticks["ranks"].items():
+                mine = arms.get("product_shell")
+                if mine and mine["skip_tick_us"] and mine["boost_tick_us"]:
+                    host_tick["blocks"][0].setdefault("shell_ticks_ms", {})[f"ranks_{P}"] = {
+                        "skip_tick_ms": round(mine["skip_tick_us"]["median"] / 1e3, 4),
+                        "boost_tick_ms": round(mine["boost_tick_us"]["median"] / 1e3, 4)}
+            host_tick["blocks"][0]["shell_ticks_ms_are"] = ("medians of rank_ticks: the GridComp shell's whole tick under compute_once_per_day: T "
+                                                          "(skip tick: the fused host pass, no GPU call; Boost tick: OHXBoosterRun1 with OH_boost kept)")
         # the reference's own child is a BASELINE (oracle/_ref, the reference compiled in place): its figures go where
         # the baselines are, the product's stay in rank_ticks
         if shell_ticks and "ranks" in shell_ticks and cpu is not None:
