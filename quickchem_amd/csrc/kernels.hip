@@ -546,6 +546,59 @@ __device__ __forceinline__ void super_step(u32x4 (&s)[CHAINS], uint32_t (&rel)[C
   }
 }
 
+// The same step (never the last one) CHAIN BY CHAIN, each chain's next record asked for the moment its number is known:
+// chain c's two feature reads, its decisions, its gather - and only then chain c + 1, whose first feature has been asked
+// for meanwhile (the skew).  super_step above goes stage by stage through all chains and leaves the four gathers for the
+// end of the step: the LDS reads of four chains overlap nicely, but every record then has to arrive between the end of
+// one step and the start of the next, with nothing of this wave to do.  Chain by chain a record has the other chains'
+// work - three quarters of a step - to arrive in.  (r6) The ring kernels' deep steps, where the texture addresser is the
+// bound and the vector ALU has slack: C360 step 24.19 -> 23.35 ms (-3.5 %), fused fields 26.64 -> 25.81, OH Run1 slab
+// 20.02 -> 19.35, 1e-3 missing 30.9 -> 29.2, depth 14 17.47 -> 17.03; the resident (LDS) steps the same way are 6 %
+// SLOWER (their records come in tens of cycles: there the stage-by-stage overlap of the feature reads is what counts).
+// Without the sched_barrier hipcc re-merges the chains (23.56); chains in pairs 23.38; without the skew 23.52; with both
+// children's features read speculatively beside the node's own (one LDS latency less, three vector instructions more) 25.0
+// (profiles/r06_sweeps.txt).  `fetch(c, record)` starts the load of chain c's next record and returns its registers.
+template <int CHAINS, bool HAS_MISSING, class Fetch>
+__device__ __forceinline__ void super_step_by_chain(u32x4 (&s)[CHAINS], uint32_t (&rel)[CHAINS], uint32_t (&leafb)[CHAINS],
+                                                    const char* __restrict__ tile_b, Fetch fetch) {
+  asm volatile("" : "+v"(s[0]));   // one 128-bit tuple: see "pin_super" above
+  float x0_next = *reinterpret_cast<const float*>(tile_b + (s[0].w & 0x1F00u));
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) {
+    const uint32_t w = s[c].w;
+    const float x0 = x0_next;
+    if (c + 1 < CHAINS) {
+      asm volatile("" : "+v"(s[c + 1]));
+      x0_next = *reinterpret_cast<const float*>(tile_b + (s[c + 1].w & 0x1F00u));
+    }
+    uint32_t thr1, f1;
+    bool l0 = false;
+    lane_mask r0 = 0;
+    if constexpr (HAS_MISSING) {
+      r0 = right_or_default(x0, __uint_as_float(s[c].x), w, 32u);
+      thr1 = pick(r0, s[c].y, s[c].z);
+      f1 = (w >> pick(r0, 0u, 13u)) & 31u;
+    } else {
+      l0 = x0 < __uint_as_float(s[c].x);
+      thr1 = l0 ? s[c].y : s[c].z;
+      f1 = (w >> (l0 ? 0u : 13u)) & 31u;
+    }
+    const float x1 = *reinterpret_cast<const float*>(tile_b + (f1 << 8));
+    const uint32_t g = w >> 18;
+    if constexpr (HAS_MISSING) {
+      const lane_mask r1 = right_or_default(x1, __uint_as_float(thr1), w, pick(r0, 64u, 128u));
+      rel[c] = double_and_carry(double_and_carry(g, r0), r1);
+    } else {
+      const bool l1 = x1 < __uint_as_float(thr1);
+      const lane_mask right0 = __builtin_amdgcn_ballot_w64(!l0), right1 = __builtin_amdgcn_ballot_w64(!l1);
+      rel[c] = double_and_carry(double_and_carry(g, right0), right1);
+    }
+    s[c] = fetch(c, rel[c]);
+    leafb[c] = (f1 == 31u) ? thr1 : leafb[c];      // off the path to the gather: behind it (23.32 -> 23.12 ms)
+    __builtin_amdgcn_sched_barrier(0);      // the next chain's work stays behind this chain's gather
+  }
+}
+
 // `first`: the block's LDS copy of every tree's first-step super-nodes (kFirstTrees trees, two
 // entries each: the root's children, or the root's own super-node twice), filled by the kernel.
 // The first gather of a walk is the cheapest for the L1 (one block per tree) but costs the
@@ -1085,12 +1138,13 @@ __device__ __forceinline__ float ring_walk_group(const SuperTreeHead (&h)[kRingC
   }
   if (ahead) __builtin_amdgcn_s_setprio(2);      // the gathers of the deep steps first (see above)
   else __builtin_amdgcn_s_setprio(3);
-  for (uint32_t step = kRingSteps; step < nsteps; ++step) {
-    super_step<CHAINS, HAS_MISSING, false>(s, rel, leafb, tile_b);
+  uint32_t base[CHAINS];
 #pragma unroll
-    for (int c = 0; c < CHAINS; ++c)
-      s[c] = __builtin_amdgcn_raw_buffer_load_b128(forest, (int)((h[c].base + rel[c]) << 4), 0, 0);
-  }
+  for (int c = 0; c < CHAINS; ++c) base[c] = h[c].base;
+  for (uint32_t step = kRingSteps; step < nsteps; ++step)
+    super_step_by_chain<CHAINS, HAS_MISSING>(s, rel, leafb, tile_b, [&](int c, uint32_t record) -> u32x4 {
+      return __builtin_amdgcn_raw_buffer_load_b128(forest, (int)((base[c] + record) << 4), 0, 0);
+    });
   super_step<CHAINS, HAS_MISSING, true>(s, rel, leafb, tile_b);
   __builtin_amdgcn_s_setprio(1);      // the ring's bookkeeping between two groups is part of the walk (ring_walk_tile)
 #pragma unroll
