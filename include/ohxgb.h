@@ -206,7 +206,18 @@ int OHXDMatrixInferGrid(DMatrixHandle handle, void* stream, int* found);
  * kernels raised (inf in the input; without it a device form's caller never
  * learns of them).  A booster keeps single scratch buffers
  * (error flags, Run1 intermediates, staging): calls on ONE booster must not run
- * concurrently on two streams or threads; different boosters are independent. */
+ * concurrently on two streams or threads; different boosters are independent.
+ * hipGraphs: this call and OHXBoosterPredictFieldsDevice may be made on a stream
+ * that is being captured - what they enqueue is launches, memsets and copies on
+ * `stream` - once ONE plain call of the same shape has been made on the booster
+ * and the matrix (it allocates the booster's buffers, uploads the model and looks
+ * at the matrix).  A capture that would have to allocate or to wait returns -1
+ * with a message that says so and enqueues nothing.  While capturing the library
+ * leaves out what its host side does beside the launches to adapt the NEXT call
+ * (the read-back of how many rows went to the second launch): a replay walks the
+ * way the last plain call decided, and is bit-identical to a plain call on the
+ * same contents (tests/test_gpu_graph.py).  OHXBoosterRun1Device is not
+ * capturable: it waits for its slab count. */
 int OHXBoosterPredictDevice(BoosterHandle handle, DMatrixHandle dmat, int option_mask, unsigned ntree_limit,
                             float* d_out, void* stream);
 int OHXBoosterCheck(BoosterHandle handle, void* stream);

@@ -926,6 +926,9 @@ struct LevelSizeCache {
 };
 LevelSizeCache g_level_sizes;
 
+bool stream_capturing(hipStream_t stream);                 // defined with the deferred rows below
+[[noreturn]] void refuse_in_capture(const char* what);
+
 // Launches + one read-back on `stream`; waits for it (the rows must be there) - unless a matrix of this shape has
 // been searched before and `use_cache` allows taking its verdict.
 void infer_level_size(DMatrixObj& d, hipStream_t stream, bool use_cache = false) {
@@ -992,6 +995,7 @@ const uint32_t* cluster_rows(BoosterObj& b, DMatrixObj& d, const PredictArgs& a,
   HIP_CHECK(hipMemsetAsync(c.agree, 0, 9 * sizeof(uint32_t), stream));
   HIP_CHECK(launch_cluster_keys(device_forest(b), c, b.dev.num_cus, stream));
   if (b.tune.cluster < 0 && !d.cluster_decided) {
+    if (stream_capturing(stream)) refuse_in_capture("judge the order of the rows (it waits for the stream)");
     HIP_CHECK(hipMemcpyAsync(b.h_cluster_small.p, c.agree, 9 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     // observed agreement between neighbours in row order against what rows in random order would show
@@ -1063,13 +1067,36 @@ bool defer_plan(const BoosterObj& b, uint64_t nrow, LaunchTuning& tune) {
   return true;
 }
 
+// Is `stream` being captured into a hipGraph?  The device forms (OHXBoosterPredictDevice, OHXBoosterPredictFieldsDevice)
+// may be: what they enqueue is launches, memsets and copies on the caller's stream and nothing else, once the
+// booster's buffers exist and the matrix has been looked at - i.e. after one plain call of the same shape.  What the
+// host does BESIDE the launches to adapt the next call (the read-back of how many rows were left to the second launch,
+// the event query that consumes it) is left out while capturing: a replay could not repeat it, and an event query is
+// not allowed beside a capture.  The captured work is what the last plain call decided.
+bool stream_capturing(hipStream_t stream) {
+  if (stream == nullptr) return false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return st == hipStreamCaptureStatusActive;
+}
+
+[[noreturn]] void refuse_in_capture(const char* what) {
+  throw OhxError(std::string("inside a stream capture the library cannot ") + what +
+                 ": make one plain call of the same shape on this booster and matrix first, then capture");
+}
+
 bool defer_prepare(BoosterObj& b, uint64_t nrow, LaunchTuning& tune, hipStream_t stream) {
   if (tune.defer_missing == 0 || !(tune.defer_missing > 0 || nrow >= (1u << 18))) return false;
-  if (b.defer_pending && hipEventQuery(b.defer_seen) == hipSuccess) {
+  const bool capturing = stream_capturing(stream);
+  if (!capturing && b.defer_pending && hipEventQuery(b.defer_seen) == hipSuccess) {
     b.defer_pending = false;
     b.defer_too_many = (uint64_t)b.h_defer_count.p[0] * 50u > b.defer_last_nrow;        // more than 2 % of the rows
   }
   const uint32_t* before = b.d_defer.p;
+  if (capturing && b.d_defer.n < (size_t)(nrow / 32 + 1024 + 1)) refuse_in_capture("allocate the list of rows left to the second launch");
   b.d_defer.ensure((size_t)(nrow / 32 + 1024 + 1));
   // the launchers zero the count only when they really defer (kernels.hip launch_predict: prefetch kernel, no split
   // ...); defer_look reads it back regardless, so a buffer fresh from hipMalloc must not hold garbage
@@ -1083,7 +1110,7 @@ bool defer_prepare(BoosterObj& b, uint64_t nrow, LaunchTuning& tune, hipStream_t
 }
 
 void defer_look(BoosterObj& b, uint64_t nrow, hipStream_t stream) {
-  if (b.defer_pending) return;
+  if (b.defer_pending || stream_capturing(stream)) return;
   if (b.defer_seen == nullptr) HIP_CHECK(hipEventCreateWithFlags(&b.defer_seen, hipEventDisableTiming));
   b.h_defer_count.ensure(1);
   HIP_CHECK(hipMemcpyAsync(b.h_defer_count.p, b.d_defer.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1105,7 +1132,10 @@ void launch_predict_checked(BoosterObj& b, DMatrixObj& d, int option_mask, unsig
   // nobody has said which grid the rows come from: look once (work on `stream` enqueued so far is waited for)
   // (a matrix the library copied itself - the reference's create / predict / free per tick - takes the verdict of
   // the last matrix of its shape instead of looking again)
-  if (!d.grid_looked && d.grid_im == 0 && !pred_leaf && kind != KernelKind::Wide) infer_level_size(d, stream, d.owned != nullptr);
+  if (!d.grid_looked && d.grid_im == 0 && !pred_leaf && kind != KernelKind::Wide) {
+    if (stream_capturing(stream)) refuse_in_capture("look for the rows' level size (it waits for the stream)");
+    infer_level_size(d, stream, d.owned != nullptr);
+  }
   if (pred_leaf || kind == KernelKind::Wide) ensure_wide(b);
   PredictArgs a;
   a.rows = d.d_data;
